@@ -1,0 +1,309 @@
+"""ctypes binding of include/fqgpu.h (one Python name per C entry point)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libfqgpu.so")
+
+SEQ_MODELS, SEQ_ALPHA = 256, 4
+QUAL_MODELS, QUAL_ALPHA = 8192, 64
+REC_DTYPE = np.dtype([("seq_off", "<u4"), ("qual_off", "<u4"), ("len", "<u4")])
+SEQ_FT_DTYPE = np.dtype(
+    [("norm", "<i2", (SEQ_MODELS, SEQ_ALPHA)), ("logs", "<u4", (SEQ_MODELS,)), ("max_log", "<u4")]
+)
+QUAL_FT_DTYPE = np.dtype(
+    [("norm", "<i2", (QUAL_MODELS, QUAL_ALPHA)), ("logs", "<u4", (QUAL_MODELS,)), ("max_log", "<u4")]
+)
+F_WRITE_BACK_N = 1
+
+ERRORS = {0: "OK", -1: "OVERFLOW", -2: "SHORT_READ", -3: "CORRUPT", -4: "ARG", -5: "NO_DEVICE",
+          -6: "NOMEM", -7: "HIP"}
+
+
+class FqgpuError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = lib().fqgpu_strerror(code).decode() if _lib is not None else ""
+        super().__init__("fqgpu %s: %s (%d) %s" % (where, ERRORS.get(code, "?"), code, msg))
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("kernel_ms", C.c_float * 24),
+                ("kernel_name", C.c_char_p * 24), ("n_kernels", C.c_int)]
+
+
+def lib_path():
+    return LIB_PATH
+
+
+def build(verbose=False):
+    """Compile every HIP translation unit for gfx950 and link libfqgpu.so in-tree."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc"), "-j", "6"]
+    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+_PROTOS = {
+    # name: (restype, argtypes)
+    "fqgpu_device_count": (C.c_int, []),
+    "fqgpu_strerror": (C.c_char_p, [C.c_int]),
+    "fqgpu_version": (C.c_char_p, []),
+    "fqgpu_bound_seq": (C.c_size_t, [C.c_size_t]),
+    "fqgpu_bound_qual": (C.c_size_t, [C.c_size_t]),
+    "fqgpu_freq_tables": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fqgpu_tables_from_counts": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fqgpu_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "fqgpu_ctx_destroy": (None, [C.c_void_p]),
+    "fqgpu_ctx_set_chain_params": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint]),
+    "fqgpu_ctx_dump_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t]),
+    "fqgpu_encode_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                     C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_size_t), C.c_uint]),
+    "fqgpu_decode_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_size_t, C.c_void_p, C.c_size_t]),
+    "fqgpu_dblock_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_void_p)]),
+    "fqgpu_dblock_destroy": (None, [C.c_void_p]),
+    "fqgpu_dblock_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint]),
+    "fqgpu_dblock_wipe": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fqgpu_dblocks_decode": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "fqgpu_sync": (C.c_int, [C.c_void_p]),
+    "fqgpu_dblock_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "fqgpu_dblock_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fqgpu_dblock_load_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fqgpu_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "fqgpu_ctx_last_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    "fqgpu_parse_fastq": (C.c_long, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "fqgpu_synth_fastq": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_uint64,
+                                       C.POINTER(C.c_uint64)]),
+}
+EXPORTS = sorted(_PROTOS)
+
+
+def lib():
+    """The loaded extension.  Raises if libfqgpu.so has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libfqgpu.so is not built (run __graft_entry__.build() or "
+                               "`make -C fqcomp28_amd/csrc`); the product path has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)  # AttributeError = a symbol the header declares is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise FqgpuError(rc, where)
+
+
+def device_count():
+    return lib().fqgpu_device_count()
+
+
+def bound_seq(n):
+    return lib().fqgpu_bound_seq(n)
+
+
+def bound_qual(n):
+    return lib().fqgpu_bound_qual(n)
+
+
+def parse_fastq(raw):
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    n = lib().fqgpu_parse_fastq(_p(raw), raw.size, None, 0)
+    if n < 0:
+        raise FqgpuError(-4, "parse_fastq")
+    recs = np.zeros(n, dtype=REC_DTYPE)
+    lib().fqgpu_parse_fastq(_p(raw), raw.size, _p(recs), n)
+    return recs
+
+
+def synth_fastq(n_bytes, mode, seed=28, first_read_id=0):
+    """-> (uint8 array of whole records, number of reads)"""
+    buf = np.empty(n_bytes, dtype=np.uint8)
+    n_reads = C.c_uint64(0)
+    used = lib().fqgpu_synth_fastq(_p(buf), n_bytes, mode, seed, first_read_id, C.byref(n_reads))
+    return buf[:used], int(n_reads.value)
+
+
+def freq_tables(raw, recs, device=0, want_counts=False):
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    sft = np.zeros(1, dtype=SEQ_FT_DTYPE)
+    qft = np.zeros(1, dtype=QUAL_FT_DTYPE)
+    sc = np.zeros((SEQ_MODELS, SEQ_ALPHA), dtype=np.uint32) if want_counts else None
+    qc = np.zeros((QUAL_MODELS, QUAL_ALPHA), dtype=np.uint32) if want_counts else None
+    _check(lib().fqgpu_freq_tables(device, _p(raw), raw.size, _p(recs), len(recs), _p(sft), _p(qft),
+                                   _p(sc), _p(qc)), "freq_tables")
+    return (sft, qft, sc, qc) if want_counts else (sft, qft)
+
+
+def tables_from_counts(seq_counts, qual_counts, device=0):
+    sft = np.zeros(1, dtype=SEQ_FT_DTYPE)
+    qft = np.zeros(1, dtype=QUAL_FT_DTYPE)
+    sc = np.ascontiguousarray(seq_counts, dtype=np.uint32)
+    qc = np.ascontiguousarray(qual_counts, dtype=np.uint32)
+    _check(lib().fqgpu_tables_from_counts(device, _p(sc), _p(qc), _p(sft), _p(qft)), "tables_from_counts")
+    return sft, qft
+
+
+class DBlock:
+    """Device-resident block (fqgpu_dblock)."""
+
+    def __init__(self, ctx, raw, recs):
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+        self.ctx = ctx
+        self.raw_len, self.n_recs = raw.size, len(recs)
+        h = C.c_void_p()
+        _check(lib().fqgpu_dblock_create(ctx.h, _p(raw), raw.size, _p(recs), len(recs), C.byref(h)),
+               "dblock_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fqgpu_dblock_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def encode(self, flags=0):
+        _check(lib().fqgpu_dblock_encode(self.ctx.h, self.h, flags), "dblock_encode")
+
+    def wipe(self):
+        _check(lib().fqgpu_dblock_wipe(self.ctx.h, self.h), "dblock_wipe")
+
+    def status(self):
+        a, b, c, d = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        rc = lib().fqgpu_dblock_status(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return rc, dict(seq_len=a.value, qual_len=b.value, n_pos_len=c.value, n_bases=d.value)
+
+    def fetch(self, raw=False):
+        rc, st = self.status()
+        _check(rc, "dblock_status")
+        seq = np.zeros(st["seq_len"], dtype=np.uint8)
+        qual = np.zeros(st["qual_len"], dtype=np.uint8)
+        rl = np.zeros(self.n_recs, dtype=np.uint16)
+        nc = np.zeros(self.n_recs, dtype=np.uint16)
+        npos = np.zeros(st["n_pos_len"], dtype=np.uint16)
+        rw = np.zeros(self.raw_len, dtype=np.uint8) if raw else None
+        _check(lib().fqgpu_dblock_fetch(self.ctx.h, self.h, _p(seq), _p(qual), _p(rl), _p(nc), _p(npos),
+                                        _p(rw)), "dblock_fetch")
+        return dict(seq=seq, qual=qual, readlens=rl, n_count=nc, n_pos=npos, raw=rw)
+
+    def fetch_raw(self):
+        rw = np.zeros(self.raw_len, dtype=np.uint8)
+        _check(lib().fqgpu_dblock_fetch(self.ctx.h, self.h, None, None, None, None, None, _p(rw)),
+               "dblock_fetch")
+        return rw
+
+    def load_streams(self, seq, qual, n_count, n_pos):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        n_count = np.ascontiguousarray(n_count, dtype=np.uint16)
+        n_pos = np.ascontiguousarray(n_pos, dtype=np.uint16)
+        _check(lib().fqgpu_dblock_load_streams(self.ctx.h, self.h, _p(seq), seq.size, _p(qual), qual.size,
+                                               _p(n_count), _p(n_pos), n_pos.size), "load_streams")
+
+
+class Context:
+    """fqgpu_ctx: the device-side equivalent of a reference Compression/DecompressionWorkspace."""
+
+    def __init__(self, seq_ft, qual_ft, device=0):
+        self.seq_ft = np.ascontiguousarray(seq_ft)
+        self.qual_ft = np.ascontiguousarray(qual_ft)
+        assert self.seq_ft.nbytes == SEQ_FT_DTYPE.itemsize and self.qual_ft.nbytes == QUAL_FT_DTYPE.itemsize
+        h = C.c_void_p()
+        _check(lib().fqgpu_ctx_create(device, _p(self.seq_ft), _p(self.qual_ft), C.byref(h)), "ctx_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fqgpu_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_chain_params(self, segment=0, warmup=0):
+        _check(lib().fqgpu_ctx_set_chain_params(self.h, segment, warmup), "set_chain_params")
+
+    def sync(self):
+        _check(lib().fqgpu_sync(self.h), "sync")
+
+    def enable_timing(self, on=True):
+        _check(lib().fqgpu_ctx_enable_timing(self.h, 1 if on else 0), "enable_timing")
+
+    def last_timing(self):
+        t = Timing()
+        _check(lib().fqgpu_ctx_last_timing(self.h, C.byref(t)), "last_timing")
+        return t.total_ms, [(t.kernel_name[i].decode(), t.kernel_ms[i]) for i in range(t.n_kernels)]
+
+    def dump_tables(self, stream, model):
+        alpha = QUAL_ALPHA if stream else SEQ_ALPHA
+        ct = np.zeros(1 + 2048 + 2 * alpha, dtype=np.uint32)
+        dt = np.zeros(1 + 4096, dtype=np.uint32)
+        _check(lib().fqgpu_ctx_dump_tables(self.h, stream, model, _p(ct), ct.size, _p(dt), dt.size),
+               "dump_tables")
+        log = int(ct[0] & 0xFFFF)
+        return ct[: 1 + (1 << (log - 1)) + 2 * alpha].copy(), dt[: 1 + (1 << log)].copy()
+
+    def dblock(self, raw, recs):
+        return DBlock(self, raw, recs)
+
+    def decode_dblocks(self, blocks):
+        arr = (C.c_void_p * len(blocks))(*[b.h for b in blocks])
+        _check(lib().fqgpu_dblocks_decode(self.h, arr, len(blocks)), "dblocks_decode")
+
+    def encode_block(self, raw, recs, flags=0, seq_cap=None, qual_cap=None):
+        """Host-pointer call (fqgpu_encode_block) -> dict like the oracle's."""
+        raw = np.array(raw, dtype=np.uint8, copy=True)
+        recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+        n = len(recs)
+        bases = int(recs["len"].sum())
+        seq_cap = bound_seq(bases) if seq_cap is None else seq_cap
+        qual_cap = bound_qual(bases) if qual_cap is None else qual_cap
+        seq = np.zeros(seq_cap, dtype=np.uint8)
+        qual = np.zeros(qual_cap, dtype=np.uint8)
+        rl = np.zeros(n, dtype=np.uint16)
+        nc = np.zeros(n, dtype=np.uint16)
+        npos = np.zeros(bases + 1, dtype=np.uint16)
+        sl, ql, nn = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        rc = lib().fqgpu_encode_block(self.h, _p(raw), raw.size, _p(recs), n, _p(seq), seq_cap, C.byref(sl),
+                                      _p(qual), qual_cap, C.byref(ql), _p(rl), _p(nc), _p(npos), npos.size,
+                                      C.byref(nn), flags)
+        return dict(rc=rc, seq=seq[: sl.value].copy(), qual=qual[: ql.value].copy(), readlens=rl, n_count=nc,
+                    n_pos=npos[: nn.value].copy(), raw_after=raw)
+
+    def decode_block(self, seq, qual, n_count, n_pos, recs, raw_skeleton):
+        out = np.array(raw_skeleton, dtype=np.uint8, copy=True)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        n_count = np.ascontiguousarray(n_count, dtype=np.uint16)
+        n_pos = np.ascontiguousarray(n_pos, dtype=np.uint16)
+        recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+        rc = lib().fqgpu_decode_block(self.h, _p(seq), seq.size, _p(qual), qual.size, _p(n_count), n_count.size,
+                                      _p(n_pos), n_pos.size, _p(recs), len(recs), _p(out), out.size)
+        return rc, out

@@ -1,0 +1,568 @@
+// C ABI of libfqgpu.so (include/fqgpu.h): handle and buffer management around the
+// kernels of tables.hip / encode.hip / decode.hip.  Host code only.
+#include "fqgpu_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_hip_msg[256] = "";
+
+int fq_hip_error(hipError_t e, const char *file, int line) {
+  snprintf(g_hip_msg, sizeof(g_hip_msg), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+  if (getenv("FQGPU_VERBOSE")) fprintf(stderr, "fqgpu: %s\n", g_hip_msg);
+  return (e == hipErrorOutOfMemory) ? FQGPU_E_NOMEM
+         : (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? FQGPU_E_NO_DEVICE
+                                                                 : FQGPU_E_HIP;
+}
+
+extern "C" const char *fqgpu_strerror(int code) {
+  switch (code) {
+  case FQGPU_OK: return "ok";
+  case FQGPU_E_OVERFLOW: return "compressed stream exceeds the reference capacity bound";
+  case FQGPU_E_SHORT_READ: return "read shorter than 3 bases (undefined in the reference coder)";
+  case FQGPU_E_CORRUPT: return "corrupt stream (end mark / leftover bits / N table)";
+  case FQGPU_E_ARG: return "bad argument or symbol outside the model alphabet";
+  case FQGPU_E_NO_DEVICE: return "no usable MI355X / HIP device (there is no CPU fallback)";
+  case FQGPU_E_NOMEM: return "out of device or host memory";
+  case FQGPU_E_HIP: return g_hip_msg[0] ? g_hip_msg : "HIP runtime error";
+  default: return "unknown fqgpu error";
+  }
+}
+
+extern "C" const char *fqgpu_version(void) { return "fqgpu 0.1 (gfx950)"; }
+
+extern "C" int fqgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// Workspace::compressBoundSequence / compressBoundQuality (reference src/workspace.h:21-35)
+extern "C" size_t fqgpu_bound_seq(size_t n) {
+  if (n < 1024) return (size_t)1024 * FQGPU_SEQ_MODELS;
+  return n / 4 + 1024;
+}
+extern "C" size_t fqgpu_bound_qual(size_t n) {
+  const size_t a = (size_t)1024 * FQGPU_QUAL_MODELS, b = n * 7 / 8 + 1024;
+  return a > b ? a : b;
+}
+
+static int use_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FQGPU_E_NO_DEVICE;
+  if (device < 0 || device >= n) return FQGPU_E_NO_DEVICE;
+  FQ_HIP(hipSetDevice(device));
+  return FQGPU_OK;
+}
+
+// ------------------------------------------------------------------ kernel timing
+struct KernelTimer {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  std::vector<const char *> names;  // names[i] labels the span ending at event i+1
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+
+void fq_timer_begin(fqgpu_ctx *ctx) {
+  KernelTimer *t = ctx->timer;
+  if (!t || !t->on) return;
+  t->used = 0;
+  t->names.clear();
+  hipEvent_t e = t->get();
+  if (e) (void)hipEventRecord(e, ctx->stream);
+}
+void fq_timer_mark(fqgpu_ctx *ctx, const char *name) {
+  KernelTimer *t = ctx->timer;
+  if (!t || !t->on || t->used == 0) return;
+  hipEvent_t e = t->get();
+  if (e) { (void)hipEventRecord(e, ctx->stream); t->names.push_back(name); }
+}
+void fq_timer_end(fqgpu_ctx *) {}
+
+extern "C" int fqgpu_ctx_enable_timing(fqgpu_ctx *ctx, int on) {
+  if (!ctx) return FQGPU_E_ARG;
+  if (!ctx->timer) ctx->timer = new (std::nothrow) KernelTimer();
+  if (!ctx->timer) return FQGPU_E_NOMEM;
+  ctx->timer->on = on != 0;
+  ctx->timer->used = 0;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_ctx_last_timing(fqgpu_ctx *ctx, fqgpu_timing *out) {
+  if (!ctx || !out || !ctx->timer) return FQGPU_E_ARG;
+  KernelTimer *t = ctx->timer;
+  memset(out, 0, sizeof(*out));
+  if (t->used < 2) return FQGPU_OK;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  FQ_HIP(hipEventSynchronize(t->pool[t->used - 1]));
+  FQ_HIP(hipEventElapsedTime(&out->total_ms, t->pool[0], t->pool[t->used - 1]));
+  // spans with the same label (there are none today) would be merged here
+  int n = 0;
+  for (size_t i = 0; i + 1 < t->used && n < 24; i++) {
+    float ms = 0;
+    FQ_HIP(hipEventElapsedTime(&ms, t->pool[i], t->pool[i + 1]));
+    out->kernel_ms[n] = ms;
+    out->kernel_name[n] = t->names[i];
+    n++;
+  }
+  out->n_kernels = n;
+  return FQGPU_OK;
+}
+
+// ------------------------------------------------------------------ record validation (host)
+static int check_recs(const fqgpu_rec *recs, size_t n_recs, size_t raw_len, size_t *n_bases) {
+  size_t tot = 0;
+  for (size_t i = 0; i < n_recs; i++) {
+    const fqgpu_rec &r = recs[i];
+    if (r.len > 65535u) return FQGPU_E_ARG;  // readlen_t is u16 (src/defs.h:14)
+    if ((size_t)r.seq_off + r.len > raw_len || (size_t)r.qual_off + r.len > raw_len) return FQGPU_E_ARG;
+    if (r.len < 3) return FQGPU_E_SHORT_READ;
+    tot += r.len;
+  }
+  if (tot >= 0xFFF00000ull) return FQGPU_E_ARG;  // block sizes are u32 in the reference too
+  *n_bases = tot;
+  return FQGPU_OK;
+}
+
+// ------------------------------------------------------------------ frequency tables
+struct FtLayout {
+  int n_models, alpha;
+  size_t norm_bytes, logs_off, maxlog_off, total;
+};
+static FtLayout ft_layout(int stream) {
+  FtLayout l;
+  l.n_models = stream ? FQGPU_QUAL_MODELS : FQGPU_SEQ_MODELS;
+  l.alpha = stream ? FQGPU_QUAL_ALPHA : FQGPU_SEQ_ALPHA;
+  l.norm_bytes = (size_t)l.n_models * l.alpha * 2;
+  l.logs_off = l.norm_bytes;
+  l.maxlog_off = l.logs_off + (size_t)l.n_models * 4;
+  l.total = l.maxlog_off + 4;
+  return l;
+}
+
+// counts (device) -> FreqTable POD (host)
+static int normalize_to_host(hipStream_t st, const uint32_t *counts_dev, int stream, void *ft_out) {
+  const FtLayout l = ft_layout(stream);
+  uint8_t *dev = fq_dev_alloc<uint8_t>(l.total + 8);
+  if (!dev) return FQGPU_E_NOMEM;
+  int rc = FQGPU_OK;
+  uint32_t err = 0;
+  do {
+    if (hipMemsetAsync(dev, 0, l.total + 8, st) != hipSuccess) { rc = FQGPU_E_HIP; break; }
+    uint32_t *err_dev = reinterpret_cast<uint32_t *>(dev + ((l.total + 3) & ~(size_t)3));
+    rc = fq_normalize_counts(st, counts_dev, l.n_models, l.alpha, reinterpret_cast<int16_t *>(dev),
+                             reinterpret_cast<uint32_t *>(dev + l.logs_off),
+                             reinterpret_cast<uint32_t *>(dev + l.maxlog_off), err_dev);
+    if (rc) break;
+    if (hipMemcpyAsync(ft_out, dev, l.total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&err, err_dev, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { rc = FQGPU_E_HIP; break; }
+    if (err) rc = FQGPU_E_ARG;
+  } while (0);
+  (void)hipFree(dev);
+  return rc;
+}
+
+extern "C" int fqgpu_tables_from_counts(int device, const uint32_t *seq_counts, const uint32_t *qual_counts,
+                                        void *seq_ft_out, void *qual_ft_out) {
+  int rc = use_device(device);
+  if (rc) return rc;
+  if (!seq_counts || !qual_counts || !seq_ft_out || !qual_ft_out) return FQGPU_E_ARG;
+  const size_t ns = (size_t)FQGPU_SEQ_MODELS * FQGPU_SEQ_ALPHA, nq = (size_t)FQGPU_QUAL_MODELS * FQGPU_QUAL_ALPHA;
+  uint32_t *dev = fq_dev_alloc<uint32_t>(ns + nq);
+  if (!dev) return FQGPU_E_NOMEM;
+  hipStream_t st = nullptr;
+  if (hipMemcpy(dev, seq_counts, ns * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(dev + ns, qual_counts, nq * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FQGPU_E_HIP;
+  if (!rc) rc = normalize_to_host(st, dev, 0, seq_ft_out);
+  if (!rc) rc = normalize_to_host(st, dev + ns, 1, qual_ft_out);
+  (void)hipFree(dev);
+  return rc;
+}
+
+extern "C" int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
+                                 size_t n_recs, void *seq_ft_out, void *qual_ft_out,
+                                 uint32_t *seq_counts_out, uint32_t *qual_counts_out) {
+  int rc = use_device(device);
+  if (rc) return rc;
+  if (!raw || !recs || !seq_ft_out || !qual_ft_out) return FQGPU_E_ARG;
+  // the histogram pass itself accepts reads of any length (src/fse_sequence.cpp:145-169)
+  for (size_t i = 0; i < n_recs; i++)
+    if ((size_t)recs[i].seq_off + recs[i].len > raw_len || (size_t)recs[i].qual_off + recs[i].len > raw_len)
+      return FQGPU_E_ARG;
+  const size_t ns = (size_t)FQGPU_SEQ_MODELS * FQGPU_SEQ_ALPHA, nq = (size_t)FQGPU_QUAL_MODELS * FQGPU_QUAL_ALPHA;
+  uint8_t *raw_dev = fq_dev_alloc<uint8_t>(raw_len + 64);
+  fqgpu_rec *recs_dev = fq_dev_alloc<fqgpu_rec>(n_recs + 1);
+  uint32_t *cnt = fq_dev_alloc<uint32_t>(ns + nq + 1);
+  hipStream_t st = nullptr;
+  uint32_t err = 0;
+  if (!raw_dev || !recs_dev || !cnt) rc = FQGPU_E_NOMEM;
+  do {
+    if (rc) break;
+    if (hipMemcpy(raw_dev, raw, raw_len, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(recs_dev, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(cnt + ns + nq, 0, 4) != hipSuccess) { rc = FQGPU_E_HIP; break; }
+    if ((rc = fq_build_freq_tables(device, st, raw_dev, recs_dev, n_recs, cnt, cnt + ns))) break;
+    if (hipMemcpy(&err, cnt + ns + nq, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = FQGPU_E_HIP; break; }
+    if (err) { rc = FQGPU_E_ARG; break; }  // quality above Q63: the reference throws (src/fse_quality.cpp:88)
+    if (seq_counts_out && hipMemcpy(seq_counts_out, cnt, ns * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = FQGPU_E_HIP; break; }
+    if (qual_counts_out && hipMemcpy(qual_counts_out, cnt + ns, nq * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = FQGPU_E_HIP; break; }
+    if ((rc = normalize_to_host(st, cnt, 0, seq_ft_out))) break;
+    if ((rc = normalize_to_host(st, cnt + ns, 1, qual_ft_out))) break;
+  } while (0);
+  if (raw_dev) (void)hipFree(raw_dev);
+  if (recs_dev) (void)hipFree(recs_dev);
+  if (cnt) (void)hipFree(cnt);
+  return rc;
+}
+
+// ------------------------------------------------------------------ handle
+static void free_tables(DevTables &t) {
+  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off};
+  for (void *p : ps) if (p) (void)hipFree(p);
+  t = DevTables();
+}
+
+static int upload_tables(fqgpu_ctx *ctx, int stream, const void *ft) {
+  const FtLayout l = ft_layout(stream);
+  DevTables &t = ctx->tab[stream];
+  const uint8_t *p = static_cast<const uint8_t *>(ft);
+  const uint32_t *logs = reinterpret_cast<const uint32_t *>(p + l.logs_off);
+  uint32_t max_log = 0;
+  for (int i = 0; i < l.n_models; i++) {
+    if (logs[i] < 5 || logs[i] > 12) return FQGPU_E_ARG;  // FSE_MIN_TABLELOG .. FSE_MAX_TABLELOG
+    if (logs[i] > max_log) max_log = logs[i];
+  }
+  t.max_log = max_log;
+  t.norm = fq_dev_alloc<int16_t>((size_t)l.n_models * l.alpha);
+  t.logs = fq_dev_alloc<uint32_t>(l.n_models);
+  uint32_t *err_dev = fq_dev_alloc<uint32_t>(1);
+  if (!t.norm || !t.logs || !err_dev) return FQGPU_E_NOMEM;
+  FQ_HIP(hipMemcpyAsync(t.norm, p, l.norm_bytes, hipMemcpyHostToDevice, ctx->stream));
+  FQ_HIP(hipMemcpyAsync(t.logs, logs, (size_t)l.n_models * 4, hipMemcpyHostToDevice, ctx->stream));
+  FQ_HIP(hipMemsetAsync(err_dev, 0, 4, ctx->stream));
+  int rc = fq_build_tables(ctx->stream, t, l.n_models, l.alpha, err_dev);
+  uint32_t err = 0;
+  if (!rc) {
+    FQ_HIP(hipMemcpyAsync(&err, err_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (err) rc = FQGPU_E_ARG;  // counts of a context do not sum to 2^log
+  }
+  (void)hipFree(err_dev);
+  return rc;
+}
+
+extern "C" int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual_ft, fqgpu_ctx **out) {
+  if (!out) return FQGPU_E_ARG;
+  *out = nullptr;
+  int rc = use_device(device);
+  if (rc) return rc;
+  if (!seq_ft || !qual_ft) return FQGPU_E_ARG;
+  fqgpu_ctx *ctx = new (std::nothrow) fqgpu_ctx();
+  if (!ctx) return FQGPU_E_NOMEM;
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return FQGPU_E_HIP;
+  }
+  rc = upload_tables(ctx, 0, seq_ft);
+  if (!rc) rc = upload_tables(ctx, 1, qual_ft);
+  if (rc) { fqgpu_ctx_destroy(ctx); return rc; }
+  *out = ctx;
+  return FQGPU_OK;
+}
+
+extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_tables(ctx->tab[0]);
+  free_tables(ctx->tab[1]);
+  DevBuf *bufs[] = {&ctx->rec_start, &ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc, &ctx->tmp_result};
+  for (DevBuf *b : bufs) b->release();
+  for (int s = 0; s < 2; s++) {
+    EncScratch &e = ctx->enc[s];
+    DevBuf *eb[] = {&e.slot_of, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
+                    &e.ctx_arrays, &e.seg_state, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
+    for (DevBuf *b : eb) b->release();
+  }
+  if (ctx->timer) {
+    for (hipEvent_t e : ctx->timer->pool) (void)hipEventDestroy(e);
+    delete ctx->timer;
+  }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned warmup) {
+  if (!ctx) return FQGPU_E_ARG;
+  if (segment) {
+    if (segment < 4 || segment > (1u << 20)) return FQGPU_E_ARG;
+    ctx->seg_len = segment;
+  }
+  ctx->warmup = warmup == 0xFFFFFFFFu ? 0 : (warmup ? warmup : ctx->warmup);
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_ctx_dump_tables(fqgpu_ctx *ctx, int stream, unsigned model, uint32_t *ctable_out,
+                                     size_t ctable_cap_words, uint32_t *dtable_out, size_t dtable_cap_words) {
+  if (!ctx || stream < 0 || stream > 1) return FQGPU_E_ARG;
+  const FtLayout l = ft_layout(stream);
+  if (model >= (unsigned)l.n_models) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  const DevTables &t = ctx->tab[stream];
+  uint32_t lg = 0, co = 0, dof = 0;
+  FQ_HIP(hipMemcpy(&lg, t.logs + model, 4, hipMemcpyDeviceToHost));
+  FQ_HIP(hipMemcpy(&co, t.ct_off + model, 4, hipMemcpyDeviceToHost));
+  FQ_HIP(hipMemcpy(&dof, t.dt_off + model, 4, hipMemcpyDeviceToHost));
+  const size_t cw = 1 + ((size_t)1 << (lg - 1)) + 2 * (size_t)l.alpha, dw = 1 + ((size_t)1 << lg);
+  if (ctable_out) {
+    if (ctable_cap_words < cw) return FQGPU_E_ARG;
+    FQ_HIP(hipMemcpy(ctable_out, t.ct + co, cw * 4, hipMemcpyDeviceToHost));
+  }
+  if (dtable_out) {
+    if (dtable_cap_words < dw) return FQGPU_E_ARG;
+    FQ_HIP(hipMemcpy(dtable_out, t.dt + dof, dw * 4, hipMemcpyDeviceToHost));
+  }
+  return FQGPU_OK;
+}
+
+// ------------------------------------------------------------------ device-resident blocks
+extern "C" void fqgpu_dblock_destroy(fqgpu_dblock *b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  void *ps[] = {b->raw, b->recs, b->seq, b->qual, b->readlens, b->n_count, b->n_pos, b->result};
+  for (void *p : ps) if (p) (void)hipFree(p);
+  delete b;
+}
+
+extern "C" int fqgpu_dblock_create(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
+                                   size_t n_recs, fqgpu_dblock **out) {
+  if (!ctx || !raw || !recs || !out || !n_recs) return FQGPU_E_ARG;
+  *out = nullptr;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  size_t n_bases = 0;
+  if ((rc = check_recs(recs, n_recs, raw_len, &n_bases))) return rc;
+  // number of N bases = entries of n_pos (the reference grows the vector as it goes)
+  size_t n_n = 0;
+  for (size_t i = 0; i < n_recs; i++) {
+    const uint8_t *s = raw + recs[i].seq_off, *e = s + recs[i].len;
+    while ((s = static_cast<const uint8_t *>(memchr(s, 'N', (size_t)(e - s)))) != nullptr) { n_n++; s++; }
+  }
+  fqgpu_dblock *b = new (std::nothrow) fqgpu_dblock();
+  if (!b) return FQGPU_E_NOMEM;
+  b->device = ctx->device;
+  b->raw_len = raw_len; b->n_recs = n_recs; b->n_bases = n_bases;
+  b->seq_cap = fqgpu_bound_seq(n_bases);
+  b->qual_cap = fqgpu_bound_qual(n_bases);
+  b->n_pos_cap = n_n;
+  b->raw = fq_dev_alloc<uint8_t>(raw_len + 64);
+  b->recs = fq_dev_alloc<fqgpu_rec>(n_recs);
+  b->seq = fq_dev_alloc<uint8_t>(b->seq_cap + 64);
+  b->qual = fq_dev_alloc<uint8_t>(b->qual_cap + 64);
+  b->readlens = fq_dev_alloc<uint16_t>(n_recs);
+  b->n_count = fq_dev_alloc<uint16_t>(n_recs);
+  b->n_pos = fq_dev_alloc<uint16_t>(n_n + 16);
+  b->result = fq_dev_alloc<BlockResult>(1);
+  if (!b->raw || !b->recs || !b->seq || !b->qual || !b->readlens || !b->n_count || !b->n_pos || !b->result) {
+    fqgpu_dblock_destroy(b);
+    return FQGPU_E_NOMEM;
+  }
+  hipError_t he = hipMemcpyAsync(b->raw, raw, raw_len, hipMemcpyHostToDevice, ctx->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, ctx->stream);
+  if (he == hipSuccess) he = hipMemsetAsync(b->result, 0, sizeof(BlockResult), ctx->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+  if (he != hipSuccess) { fqgpu_dblock_destroy(b); return fq_hip_error(he, __FILE__, __LINE__); }
+  memset(&b->host_result, 0, sizeof(b->host_result));
+  *out = b;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_encode(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
+  if (!ctx || !b || b->device != ctx->device) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  b->last_op = 1;
+  return fq_encode_launch(ctx, b, flags);
+}
+
+extern "C" int fqgpu_dblock_wipe(fqgpu_ctx *ctx, fqgpu_dblock *b) {
+  if (!ctx || !b || b->device != ctx->device) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  return fq_wipe_launch(ctx, b);
+}
+
+extern "C" int fqgpu_sync(fqgpu_ctx *ctx) {
+  if (!ctx) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  return FQGPU_OK;
+}
+
+// Reads the device result block; call after fqgpu_sync.  Encode results also set the
+// stream sizes a later decode of this block uses.
+static int pull_result(fqgpu_dblock *b, bool from_encode) {
+  FQ_HIP(hipMemcpy(&b->host_result, b->result, sizeof(BlockResult), hipMemcpyDeviceToHost));
+  const BlockResult &r = b->host_result;
+  if (r.s[1].bad_symbol || r.s[0].bad_symbol) return FQGPU_E_ARG;
+  if (from_encode) {
+    if (r.s[0].overflow || r.s[1].overflow) return FQGPU_E_OVERFLOW;
+    b->seq_len = (size_t)r.s[0].len;
+    b->qual_len = (size_t)r.s[1].len;
+    b->n_pos_len = (size_t)r.n_pos_len;
+  } else if (r.s[0].corrupt || r.s[1].corrupt) {
+    return FQGPU_E_CORRUPT;
+  }
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_t *qual_len, size_t *n_pos_len,
+                                   size_t *n_bases) {
+  if (!b) return FQGPU_E_ARG;
+  fqgpu_dblock *mb = const_cast<fqgpu_dblock *>(b);
+  (void)hipSetDevice(b->device);
+  int rc = b->last_op ? pull_result(mb, b->last_op == 1) : FQGPU_OK;
+  if (seq_len) *seq_len = b->seq_len;
+  if (qual_len) *qual_len = b->qual_len;
+  if (n_pos_len) *n_pos_len = b->n_pos_len;
+  if (n_bases) *n_bases = b->n_bases;
+  return rc;
+}
+
+extern "C" int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t *seq_out, uint8_t *qual_out,
+                                  uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
+                                  uint8_t *raw_out) {
+  if (!ctx || !b) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  if (seq_out && b->seq_len) FQ_HIP(hipMemcpy(seq_out, b->seq, b->seq_len, hipMemcpyDeviceToHost));
+  if (qual_out && b->qual_len) FQ_HIP(hipMemcpy(qual_out, b->qual, b->qual_len, hipMemcpyDeviceToHost));
+  if (readlens_out) FQ_HIP(hipMemcpy(readlens_out, b->readlens, b->n_recs * 2, hipMemcpyDeviceToHost));
+  if (n_count_out) FQ_HIP(hipMemcpy(n_count_out, b->n_count, b->n_recs * 2, hipMemcpyDeviceToHost));
+  if (n_pos_out && b->n_pos_len) FQ_HIP(hipMemcpy(n_pos_out, b->n_pos, b->n_pos_len * 2, hipMemcpyDeviceToHost));
+  if (raw_out) FQ_HIP(hipMemcpy(raw_out, b->raw, b->raw_len, hipMemcpyDeviceToHost));
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint8_t *seq, size_t seq_len,
+                                         const uint8_t *qual, size_t qual_len, const uint16_t *n_count,
+                                         const uint16_t *n_pos, size_t n_pos_len) {
+  if (!ctx || !b || !seq || !qual || !n_count || (!n_pos && n_pos_len)) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  // foreign streams may be larger than what this block's own encode would need
+  if (seq_len + 64 > b->seq_cap + 64) {
+    (void)hipFree(b->seq);
+    b->seq = fq_dev_alloc<uint8_t>(seq_len + 64);
+    b->seq_cap = seq_len;
+  }
+  if (qual_len + 64 > b->qual_cap + 64) {
+    (void)hipFree(b->qual);
+    b->qual = fq_dev_alloc<uint8_t>(qual_len + 64);
+    b->qual_cap = qual_len;
+  }
+  if (n_pos_len > b->n_pos_cap) {
+    (void)hipFree(b->n_pos);
+    b->n_pos = fq_dev_alloc<uint16_t>(n_pos_len + 16);
+    b->n_pos_cap = n_pos_len;
+  }
+  if (!b->seq || !b->qual || !b->n_pos) return FQGPU_E_NOMEM;
+  FQ_HIP(hipMemset(b->seq + seq_len, 0, 16));  // the bit reader loads whole dwords
+  FQ_HIP(hipMemset(b->qual + qual_len, 0, 16));
+  FQ_HIP(hipMemcpy(b->seq, seq, seq_len, hipMemcpyHostToDevice));
+  FQ_HIP(hipMemcpy(b->qual, qual, qual_len, hipMemcpyHostToDevice));
+  FQ_HIP(hipMemcpy(b->n_count, n_count, b->n_recs * 2, hipMemcpyHostToDevice));
+  if (n_pos_len) FQ_HIP(hipMemcpy(b->n_pos, n_pos, n_pos_len * 2, hipMemcpyHostToDevice));
+  b->seq_len = seq_len; b->qual_len = qual_len; b->n_pos_len = n_pos_len;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblocks_decode(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks) {
+  if (!ctx || (!blocks && n_blocks)) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  for (size_t i = 0; i < n_blocks; i++)
+    if (!blocks[i] || blocks[i]->device != ctx->device || !blocks[i]->seq_len || !blocks[i]->qual_len)
+      return FQGPU_E_ARG;
+  for (size_t i = 0; i < n_blocks; i++) blocks[i]->last_op = 2;
+  return fq_decode_launch(ctx, blocks, n_blocks);
+}
+
+// ------------------------------------------------------------------ host-pointer convenience calls
+extern "C" int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
+                                  size_t n_recs, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
+                                  uint8_t *qual_out, size_t qual_cap, size_t *qual_len,
+                                  uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
+                                  size_t n_pos_cap, size_t *n_pos_len, unsigned flags) {
+  if (!ctx || !seq_out || !qual_out || !seq_len || !qual_len) return FQGPU_E_ARG;
+  fqgpu_dblock *b = nullptr;
+  int rc = fqgpu_dblock_create(ctx, raw, raw_len, recs, n_recs, &b);
+  if (rc) return rc;
+  // the caller's capacities are the ones the overflow rule is judged against
+  if (seq_cap > b->seq_cap) {
+    (void)hipFree(b->seq);
+    b->seq = fq_dev_alloc<uint8_t>(seq_cap + 64);
+  }
+  if (qual_cap > b->qual_cap) {
+    (void)hipFree(b->qual);
+    b->qual = fq_dev_alloc<uint8_t>(qual_cap + 64);
+  }
+  if (!b->seq || !b->qual) { fqgpu_dblock_destroy(b); return FQGPU_E_NOMEM; }
+  b->seq_cap = seq_cap;
+  b->qual_cap = qual_cap;
+  do {
+    if ((rc = fq_encode_launch(ctx, b, flags))) break;
+    if ((rc = fqgpu_sync(ctx))) break;
+    if ((rc = pull_result(b, true))) break;
+    if (n_pos_out && b->n_pos_len > n_pos_cap) { rc = FQGPU_E_ARG; break; }
+    rc = fqgpu_dblock_fetch(ctx, b, seq_out, qual_out, readlens_out, n_count_out, n_pos_out,
+                            (flags & FQGPU_F_WRITE_BACK_N) ? raw : nullptr);
+    *seq_len = b->seq_len;
+    *qual_len = b->qual_len;
+    if (n_pos_len) *n_pos_len = b->n_pos_len;
+  } while (0);
+  fqgpu_dblock_destroy(b);
+  return rc;
+}
+
+extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual,
+                                  size_t qual_len, const uint16_t *n_count, size_t n_count_len,
+                                  const uint16_t *n_pos, size_t n_pos_len, const fqgpu_rec *recs,
+                                  size_t n_recs, uint8_t *raw_out, size_t raw_len) {
+  if (!ctx || !seq || !qual || !n_count || !recs || !raw_out || !seq_len || !qual_len) return FQGPU_E_ARG;
+  if (n_count_len < n_recs) return FQGPU_E_CORRUPT;
+  fqgpu_dblock *b = nullptr;
+  int rc = fqgpu_dblock_create(ctx, raw_out, raw_len, recs, n_recs, &b);
+  if (rc) return rc;
+  do {
+    // the reference pops from the END of n_count (src/fse_sequence.cpp:115-126)
+    if ((rc = fqgpu_dblock_load_streams(ctx, b, seq, seq_len, qual, qual_len, n_count + (n_count_len - n_recs),
+                                        n_pos, n_pos_len))) break;
+    fqgpu_dblock *one[1] = {b};
+    if ((rc = fq_decode_launch(ctx, one, 1))) break;
+    if ((rc = fqgpu_sync(ctx))) break;
+    if ((rc = pull_result(b, false))) break;
+    rc = fqgpu_dblock_fetch(ctx, b, nullptr, nullptr, nullptr, nullptr, nullptr, raw_out);
+  } while (0);
+  fqgpu_dblock_destroy(b);
+  return rc;
+}

@@ -1,0 +1,635 @@
+// Bit-exact parallel encoder of one (block, stream) -- replaces the per-record
+// loop of CompressionWorkspace::encodeChunk (reference src/workspace.cpp:25-31)
+// with its SequenceEncoder::encodeRecord (src/fse_sequence.cpp:53-112) /
+// QualityEncoder::encodeRecord (src/fse_quality.cpp:5-53) bodies and
+// FSE_Encoder::startChunk/endChunk (src/fse_common.hpp:77-90).
+//
+// The reference interleaves one tANS state per context into ONE bitstream:
+//   for every symbol e in encode order (records in file order, positions L-1..0):
+//       emit low nb(e) bits of state[ctx(e)];  state[ctx(e)] = T[ctx(e)][sym(e)](state)
+//   then flush all states (ctx ascending), one '1' end-mark bit, zero pad.
+// ctx(e)/sym(e) depend on the INPUT only, each context's state chain only on the
+// symbols of that context.  Hence the decomposition:
+//   K1 tile_hist / K2 layout : counting sort keys = context, per-tile histograms + scan
+//   K3 scatter               : stable partition of the symbols by context
+//   K4 chains                : every context's chain cut into segments, one lane per
+//                              segment, the context's CTable in LDS; a segment starts
+//                              from a warm-up over the preceding symbols (tANS encoder
+//                              states forget their history) and records start/end state
+//   K5 fixup                 : start(k) == end(k-1) proves a segment exact; the rare
+//                              mismatches are re-run serially from the proven state
+//   K6 bitcount/scan/pack    : per-symbol (nb,bits) gathered back into encode order,
+//                              exclusive scan of nb = bit offsets, bit packing through LDS
+//   K7 epilogue              : state flush + end mark + size/overflow
+#include "fqgpu_internal.h"
+
+namespace {
+
+constexpr unsigned TILE_SEQ = 32768;   // symbols per partition tile (one wave each in K3)
+constexpr unsigned TILE_QUAL = 65536;
+constexpr unsigned GROUP_TILES = 64;   // tiles per group in the two-level tile scan
+constexpr unsigned PACK_TILE = 4096;   // symbols per bit-packing tile
+constexpr unsigned PACK_THREADS = 256;
+constexpr unsigned PACK_PER_THREAD = PACK_TILE / PACK_THREADS;  // 16
+constexpr unsigned CTX_PAD = 16;       // every context's sorted run starts 16-aligned
+
+template <class M> constexpr unsigned tile_size() { return M::STREAM == 0 ? TILE_SEQ : TILE_QUAL; }
+
+// ------------------------------------------------------------------ record-level kernels
+
+// readlens + N count per record (replaceAndEncodeNs, src/fse_sequence.cpp:35-51, first half).
+// One wave per record, lanes stride the bases.
+__global__ void __launch_bounds__(256)
+k_readlens_ncount(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R,
+                  uint16_t *__restrict__ readlens, uint16_t *__restrict__ n_count,
+                  uint32_t *__restrict__ n_cnt32, uint32_t *__restrict__ lens32) {
+  const unsigned waves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned lane = fq_lane();
+  for (unsigned r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < R; r += waves) {
+    const fqgpu_rec rec = recs[r];
+    const uint8_t *s = raw + rec.seq_off;
+    unsigned cnt = 0;
+    for (unsigned base = 0; base < rec.len; base += 64) {
+      const unsigned i = base + lane;
+      const bool isn = i < rec.len && s[i] == 'N';
+      cnt += (unsigned)__popcll(__ballot(isn));
+    }
+    if (lane == 0) {
+      readlens[r] = (uint16_t)rec.len;
+      n_count[r] = (uint16_t)cnt;
+      n_cnt32[r] = cnt;
+      lens32[r] = rec.len;
+    }
+  }
+}
+
+// N position deltas (second half of replaceAndEncodeNs) + optional N -> A write-back
+__global__ void __launch_bounds__(256)
+k_npos(uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R,
+       const uint32_t *__restrict__ n_off, uint16_t *__restrict__ n_pos, int write_back) {
+  const unsigned waves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned lane = fq_lane();
+  for (unsigned r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < R; r += waves) {
+    const unsigned first = n_off[r];
+    if (n_off[r + 1] == first) continue;  // no N in this record
+    const fqgpu_rec rec = recs[r];
+    uint8_t *s = raw + rec.seq_off;
+    unsigned done = 0, prev = 0;  // N's written so far, position of the last one (0 before any)
+    for (unsigned base = 0; base < rec.len; base += 64) {
+      const unsigned i = base + lane;
+      const bool isn = i < rec.len && s[i] == 'N';
+      const unsigned long long m = __ballot(isn);
+      if (isn) {
+        const unsigned long long below = m & ((1ull << lane) - 1ull);
+        const unsigned p = below ? base + (63u - (unsigned)__clzll(below)) : prev;
+        n_pos[first + done + (unsigned)__popcll(below)] = (uint16_t)(i - p);
+        if (write_back) s[i] = 'A';
+      }
+      if (m) prev = base + (63u - (unsigned)__clzll(m));
+      done += (unsigned)__popcll(m);
+    }
+  }
+}
+
+__global__ void k_store_npos_len(const uint32_t *__restrict__ n_off, unsigned R, BlockResult *res) {
+  res->n_pos_len = n_off[R];
+}
+
+// ------------------------------------------------------------------ K1: per-tile context histogram
+template <class M>
+__global__ void __launch_bounds__(256)
+k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
+            const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
+            uint32_t *__restrict__ tile_hist, StreamResult *res) {
+  __shared__ uint32_t hist[M::B];
+  __shared__ unsigned s_r0, s_r1;
+  const unsigned tile = blockIdx.x;
+  const unsigned e0 = tile * T;
+  const unsigned e1 = min(e0 + T, n_sym);
+  for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x) hist[c] = 0;
+  if (threadIdx.x == 0) {
+    s_r0 = fq_locate(rec_start, 0, R - 1, e0);
+    s_r1 = fq_locate(rec_start, 0, R - 1, e1 - 1);
+  }
+  __syncthreads();
+  const unsigned r0 = s_r0, r1 = s_r1;
+  bool bad = false;
+  for (unsigned e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    const unsigned r = fq_locate(rec_start, r0, r1, e);
+    const fqgpu_rec rec = recs[r];
+    const unsigned p = rec.len - 1u - (e - rec_start[r]);
+    unsigned ctx, sym;
+    fq_sym_ctx<M>(raw, rec, p, ctx, sym);
+    bad |= sym >= (unsigned)M::A;
+    atomicAdd(&hist[ctx], 1u);
+  }
+  if (bad) atomicOr(&res->bad_symbol, 1u);
+  __syncthreads();
+  for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x)
+    tile_hist[(size_t)tile * M::B + c] = hist[c];
+}
+
+// ------------------------------------------------------------------ K2: layout of the sorted arrays
+// group_sum[g][c] = sum of tile_hist over the tiles of group g
+__global__ void __launch_bounds__(256)
+k_group_sum(const uint32_t *__restrict__ tile_hist, unsigned n_tiles, unsigned B,
+            uint32_t *__restrict__ group_sum) {
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned g = blockIdx.y;
+  if (c >= B) return;
+  const unsigned t0 = g * GROUP_TILES, t1 = min(t0 + GROUP_TILES, n_tiles);
+  uint32_t acc = 0;
+  for (unsigned t = t0; t < t1; t++) acc += tile_hist[(size_t)t * B + c];
+  group_sum[(size_t)g * B + c] = acc;
+}
+
+// One workgroup: per-context totals, exclusive scan over groups (in place), then the
+// context layout: padded start of every context's run, segment and work-item prefix sums.
+// arrays: ctx_count[B] | ctx_start[B+1] | seg_base[B+1] | item_base[B+1]
+__global__ void __launch_bounds__(1024)
+k_ctx_layout(uint32_t *__restrict__ group_sum, unsigned n_groups, unsigned B, unsigned S,
+             uint32_t *__restrict__ arrays) {
+  __shared__ unsigned part[3][1024];
+  uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
+           *item_base = seg_base + B + 1;
+  for (unsigned c = threadIdx.x; c < B; c += blockDim.x) {
+    uint32_t acc = 0;
+    for (unsigned g = 0; g < n_groups; g++) {
+      const uint32_t v = group_sum[(size_t)g * B + c];
+      group_sum[(size_t)g * B + c] = acc;
+      acc += v;
+    }
+    ctx_count[c] = acc;
+  }
+  __syncthreads();
+  // blocked scan: thread t owns contexts [t*per, (t+1)*per)
+  const unsigned per = (B + blockDim.x - 1) / blockDim.x;
+  const unsigned c0 = threadIdx.x * per, c1 = min(c0 + per, B);
+  unsigned a0 = 0, a1 = 0, a2 = 0;
+  for (unsigned c = c0; c < c1; c++) {
+    const unsigned n = ctx_count[c];
+    const unsigned nseg = (n + S - 1) / S;
+    a0 += (n + CTX_PAD - 1) & ~(CTX_PAD - 1);
+    a1 += nseg;
+    a2 += (nseg + 63) >> 6;
+  }
+  part[0][threadIdx.x] = a0; part[1][threadIdx.x] = a1; part[2][threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x < 3) {  // three short serial scans over 1024 partials
+    unsigned run = 0;
+    for (unsigned i = 0; i < blockDim.x; i++) {
+      const unsigned v = part[threadIdx.x][i];
+      part[threadIdx.x][i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  a0 = part[0][threadIdx.x]; a1 = part[1][threadIdx.x]; a2 = part[2][threadIdx.x];
+  for (unsigned c = c0; c < c1; c++) {
+    const unsigned n = ctx_count[c];
+    const unsigned nseg = (n + S - 1) / S;
+    ctx_start[c] = a0; seg_base[c] = a1; item_base[c] = a2;
+    a0 += (n + CTX_PAD - 1) & ~(CTX_PAD - 1);
+    a1 += nseg;
+    a2 += (nseg + 63) >> 6;
+  }
+  if (c1 == B && c0 < B) { ctx_start[B] = a0; seg_base[B] = a1; item_base[B] = a2; }
+}
+
+// tile_base[t][c] = ctx_start[c] + (symbols of context c in tiles before t)
+__global__ void __launch_bounds__(256)
+k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ group_sum,
+            const uint32_t *__restrict__ ctx_start, unsigned n_tiles, unsigned B,
+            uint32_t *__restrict__ tile_base) {
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned g = blockIdx.y;
+  if (c >= B) return;
+  const unsigned t0 = g * GROUP_TILES, t1 = min(t0 + GROUP_TILES, n_tiles);
+  uint32_t acc = ctx_start[c] + group_sum[(size_t)g * B + c];
+  for (unsigned t = t0; t < t1; t++) {
+    tile_base[(size_t)t * B + c] = acc;
+    acc += tile_hist[(size_t)t * B + c];
+  }
+}
+
+// ------------------------------------------------------------------ K3: stable partition by context
+// One wave per tile walks its symbols in encode order, 64 at a time; lanes with equal
+// context are ranked by lane order (ballot match), the group leader advances the
+// context's cursor in LDS.  Stability is what makes every context's run = its chain.
+template <class M>
+__global__ void __launch_bounds__(64)
+k_scatter(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
+          const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
+          const uint32_t *__restrict__ tile_base, uint8_t *__restrict__ sorted_sym,
+          uint32_t *__restrict__ slot_of) {
+  __shared__ uint32_t cursor[M::B];
+  const unsigned tile = blockIdx.x, lane = threadIdx.x;
+  const unsigned e0 = tile * T;
+  const unsigned e1 = min(e0 + T, n_sym);
+  for (unsigned c = lane; c < (unsigned)M::B; c += 64) cursor[c] = tile_base[(size_t)tile * M::B + c];
+  const unsigned r0 = fq_locate(rec_start, 0, R - 1, e0);
+  const unsigned r1 = fq_locate(rec_start, 0, R - 1, e1 - 1);
+  __syncthreads();
+  for (unsigned eb = e0; eb < e1; eb += 64) {
+    const unsigned e = eb + lane;
+    const bool valid = e < e1;
+    unsigned ctx = 0, sym = 0;
+    if (valid) {
+      const unsigned r = fq_locate(rec_start, r0, r1, e);
+      const fqgpu_rec rec = recs[r];
+      const unsigned p = rec.len - 1u - (e - rec_start[r]);
+      fq_sym_ctx<M>(raw, rec, p, ctx, sym);
+      sym &= (unsigned)(M::A - 1);
+    }
+    const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
+    const unsigned rank = fq_mbcnt(grp);
+    const unsigned cur = cursor[ctx];
+    __syncthreads();  // every lane has read its cursor before any leader advances it
+    if (valid) {
+      if (rank == 0) cursor[ctx] = cur + (unsigned)__popcll(grp);
+      const unsigned slot = cur + rank;
+      sorted_sym[slot] = (uint8_t)sym;
+      slot_of[e] = slot;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ K4: speculative state chains
+struct LdsCTable {
+  const uint16_t *state_table;
+  const uint32_t *tt;  // {deltaFindState, deltaNbBits} pairs
+  unsigned log;
+};
+
+// copies one context's CTable (zstd word layout) into LDS; all 64 lanes of the wave
+template <class M>
+__device__ __forceinline__ LdsCTable stage_ctable(uint32_t *lds, const uint32_t *__restrict__ tbl) {
+  const unsigned log = tbl[0] & 0xFFFFu;
+  const unsigned words = 1u + (1u << (log - 1)) + 2u * M::A;
+  for (unsigned i = fq_lane(); i < words; i += 64) lds[i] = tbl[i];
+  __syncthreads();
+  LdsCTable t;
+  t.log = log;
+  t.state_table = reinterpret_cast<const uint16_t *>(lds) + 2;
+  t.tt = lds + 1 + (1u << (log - 1));
+  return t;
+}
+
+// FSE_encodeSymbol (zstd fse.h) on the LDS copy: returns the packed (nb << 12 | bits)
+__device__ __forceinline__ unsigned chain_step(const LdsCTable &t, unsigned &x, unsigned sym) {
+  const int dfs = (int)t.tt[2 * sym];
+  const unsigned dnb = t.tt[2 * sym + 1];
+  const unsigned nb = (x + dnb) >> 16;
+  const unsigned out = (nb << 12) | (x & ((1u << nb) - 1u));
+  x = t.state_table[(int)(x >> nb) + dfs];
+  return out;
+}
+
+template <class M>
+__global__ void __launch_bounds__(64)
+k_chains(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
+         const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
+         const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ spec_start,
+         uint16_t *__restrict__ seg_end, unsigned S, unsigned W) {
+  extern __shared__ uint32_t lds[];
+  constexpr unsigned B = M::B;
+  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
+                 *item_base = seg_base + B + 1;
+  const unsigned item = blockIdx.x;
+  if (item >= item_base[B]) return;  // the grid is an upper bound
+  // context owning this work item: last c with item_base[c] <= item
+  unsigned lo = 0, hi = B - 1;
+  while (lo < hi) {
+    const unsigned mid = lo + ((hi - lo + 1) >> 1);
+    if (item_base[mid] <= item) lo = mid; else hi = mid - 1;
+  }
+  const unsigned c = lo;
+  const unsigned n = ctx_count[c];
+  const unsigned nseg = (n + S - 1) / S;
+  const unsigned k = (item - item_base[c]) * 64 + fq_lane();
+  const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
+  if (k >= nseg) return;
+  const unsigned base = ctx_start[c];
+  const unsigned begin = k * S;
+  const unsigned end = min(n, begin + S);
+  unsigned x = 1u << t.log;  // FSE_initCState
+  if (k > 0) {               // warm-up: outputs discarded
+    const unsigned wb = begin > W ? begin - W : 0;
+    for (unsigned i = wb; i < begin; i++) (void)chain_step(t, x, sorted_sym[base + i]);
+  }
+  const unsigned spec = x;
+  for (unsigned i = begin; i < end; i++) out16[base + i] = (uint16_t)chain_step(t, x, sorted_sym[base + i]);
+  spec_start[seg_base[c] + k] = (uint16_t)spec;
+  seg_end[seg_base[c] + k] = (uint16_t)x;
+}
+
+// ------------------------------------------------------------------ K5: verification + serial fix-up
+// Segment 0 starts from the true initial state.  If spec_start[k] == seg_end[k-1]
+// for every k, induction proves all segments exact.  A mismatching segment is re-run
+// from seg_end[k-1] (exact by induction), which may change seg_end[k] and thereby the
+// verdict on k+1.  One wave per context; lane 0 does the re-runs from an LDS table copy.
+template <class M>
+__global__ void __launch_bounds__(64)
+k_fixup(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
+        const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
+        const uint32_t *__restrict__ ct_off, const uint16_t *__restrict__ spec_start,
+        uint16_t *__restrict__ seg_end, unsigned S, StreamResult *res) {
+  extern __shared__ uint32_t lds[];
+  constexpr unsigned B = M::B;
+  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
+  const unsigned c = blockIdx.x;
+  const unsigned n = ctx_count[c];
+  const unsigned nseg = (n + S - 1) / S;
+  if (nseg <= 1) return;
+  const unsigned sb = seg_base[c], base = ctx_start[c], lane = fq_lane();
+  bool staged = false;
+  LdsCTable t = {};
+  unsigned last_fixed = 0xFFFFFFFFu, last_end = 0, n_fixed = 0;
+  for (unsigned kb = 1; kb < nseg; kb += 64) {
+    const unsigned kk = kb + lane;
+    const bool valid = kk < nseg;
+    const unsigned s = valid ? spec_start[sb + kk] : 0u;
+    unsigned ep = valid ? seg_end[sb + kk - 1] : 0u;
+    if (valid && kk - 1 == last_fixed) ep = last_end;  // value still in flight to memory
+    unsigned long long mm = __ballot(valid && s != ep);
+    while (mm) {
+      const unsigned j = (unsigned)__ffsll((long long)mm) - 1u;
+      const unsigned k = kb + j;
+      mm &= mm - 1;
+      unsigned start = __shfl(ep, (int)j);
+      const unsigned sp = __shfl(s, (int)j);
+      if (k - 1 == last_fixed) start = last_end;
+      if (start == sp) continue;  // the previous re-run made this one consistent
+      if (!staged) { t = stage_ctable<M>(lds, ct + ct_off[c]); staged = true; }
+      unsigned x = start;
+      if (lane == 0) {
+        const unsigned begin = k * S, end = min(n, begin + S);
+        for (unsigned i = begin; i < end; i++)
+          out16[base + i] = (uint16_t)chain_step(t, x, sorted_sym[base + i]);
+        seg_end[sb + k] = (uint16_t)x;
+      }
+      x = __shfl(x, 0);
+      last_fixed = k; last_end = x; n_fixed++;
+      if (j + 1 < 64 && k + 1 < nseg) {  // re-judge the next segment against the new end state
+        const unsigned sp1 = __shfl(s, (int)(j + 1));
+        if (sp1 != x) mm |= 1ull << (j + 1); else mm &= ~(1ull << (j + 1));
+      }
+    }
+  }
+  if (lane == 0 && n_fixed) atomicAdd(&res->refixed, n_fixed);
+}
+
+// ------------------------------------------------------------------ K6: bit offsets and packing
+__global__ void __launch_bounds__(PACK_THREADS)
+k_bitcount(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16, unsigned n_sym,
+           uint32_t *__restrict__ tile_bits) {
+  __shared__ unsigned wsum[PACK_THREADS / 64];
+  const unsigned e0 = blockIdx.x * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
+  unsigned bits = 0;
+#pragma unroll
+  for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
+    const unsigned e = e0 + i;
+    if (e < n_sym) bits += out16[slot_of[e]] >> 12;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) bits += __shfl_xor(bits, d);
+  if (fq_lane() == 0) wsum[threadIdx.x >> 6] = bits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+    for (unsigned i = 0; i < PACK_THREADS / 64; i++) tot += wsum[i];
+    tile_bits[blockIdx.x] = tot;
+  }
+}
+
+// size and overflow verdict once the payload bit count is known
+// (BIT_closeCStream: 0 when the write pointer reached dst+cap-8, zstd bitstream.h)
+__global__ void k_finalize(const unsigned long long *__restrict__ tile_bit_base, unsigned n_ptiles,
+                           const uint32_t *__restrict__ log_prefix, unsigned B,
+                           unsigned long long cap, StreamResult *res) {
+  const unsigned long long payload = tile_bit_base[n_ptiles];
+  const unsigned long long all = payload + log_prefix[B] + 1ull;  // + state flush + end mark
+  res->total_bits = payload;
+  res->len = (all + 7ull) >> 3;
+  res->overflow = (cap <= 8ull || (all >> 3) >= cap - 8ull) ? 1u : 0u;
+}
+
+// words shared by two packing tiles are OR-ed into, so they start from zero
+__global__ void __launch_bounds__(256)
+k_zero_bounds(const unsigned long long *__restrict__ tile_bit_base, unsigned n_ptiles,
+              uint32_t *__restrict__ out, const StreamResult *res) {
+  if (res->overflow) return;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= n_ptiles) out[tile_bit_base[t] >> 5] = 0u;
+}
+
+__global__ void __launch_bounds__(PACK_THREADS)
+k_pack(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16, unsigned n_sym,
+       const unsigned long long *__restrict__ tile_bit_base, uint32_t *__restrict__ out,
+       const StreamResult *res) {
+  __shared__ uint32_t words[PACK_TILE * 12 / 32 + 4];
+  __shared__ unsigned wsum[PACK_THREADS / 64];
+  if (res->overflow) return;
+  constexpr unsigned NW = PACK_TILE * 12 / 32 + 4;
+  for (unsigned i = threadIdx.x; i < NW; i += PACK_THREADS) words[i] = 0;
+  const unsigned long long b0 = tile_bit_base[blockIdx.x], b1 = tile_bit_base[blockIdx.x + 1];
+  const unsigned e0 = blockIdx.x * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
+  unsigned v[PACK_PER_THREAD];
+  unsigned bits = 0;
+#pragma unroll
+  for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
+    const unsigned e = e0 + i;
+    v[i] = e < n_sym ? (unsigned)out16[slot_of[e]] : 0u;
+    bits += v[i] >> 12;
+  }
+  // exclusive scan of the per-thread bit counts over the workgroup
+  unsigned inc = bits;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(inc, d);
+    if (fq_lane() >= (unsigned)d) inc += o;
+  }
+  if (fq_lane() == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  unsigned off = inc - bits;
+  for (unsigned w = 0; w < (threadIdx.x >> 6); w++) off += wsum[w];
+  // bit position relative to the first 32-bit word this tile touches
+  off += (unsigned)(b0 & 31ull);
+  unsigned long long acc = 0;
+  unsigned nacc = off & 31u, w = off >> 5;
+#pragma unroll
+  for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
+    const unsigned nb = v[i] >> 12;
+    acc |= (unsigned long long)(v[i] & 0xFFFu) << nacc;
+    nacc += nb;
+    if (nacc >= 32) {
+      atomicOr(&words[w], (uint32_t)acc);
+      acc >>= 32; nacc -= 32; w++;
+    }
+  }
+  if (nacc) atomicOr(&words[w], (uint32_t)acc);
+  __syncthreads();
+  if (b1 == b0) return;
+  const unsigned long long gw0 = b0 >> 5;
+  const unsigned nw = (unsigned)(((b1 + 31ull) >> 5) - gw0);
+  const bool tail_shared = (b1 & 31ull) != 0;
+  for (unsigned i = threadIdx.x; i < nw; i += PACK_THREADS) {
+    if (i == 0 || (tail_shared && i == nw - 1)) atomicOr(&out[gw0 + i], words[i]);
+    else out[gw0 + i] = words[i];
+  }
+}
+
+// ------------------------------------------------------------------ K7: state flush + end mark
+// FSE_Encoder::endChunk (src/fse_common.hpp:86-90): states of context 0..B-1, log bits each,
+// then one '1' bit.  A context's final state is the end state of its last segment.
+template <class M>
+__global__ void __launch_bounds__(256)
+k_epilogue(const uint32_t *__restrict__ arrays, const uint16_t *__restrict__ seg_end,
+           const uint32_t *__restrict__ logs, const uint32_t *__restrict__ log_prefix, unsigned S,
+           uint32_t *__restrict__ out, const StreamResult *res) {
+  constexpr unsigned B = M::B;
+  constexpr unsigned NW = (B * 12 + 1 + 31) / 32 + 2;
+  __shared__ uint32_t words[NW];
+  if (res->overflow) return;
+  const uint32_t *ctx_count = arrays, *seg_base = arrays + B + B + 1;
+  for (unsigned i = threadIdx.x; i < NW; i += blockDim.x) words[i] = 0;
+  __syncthreads();
+  const unsigned long long p0 = res->total_bits;
+  const unsigned sh = (unsigned)(p0 & 31ull);
+  for (unsigned c = threadIdx.x; c <= B; c += blockDim.x) {
+    unsigned val, nb;
+    if (c < B) {
+      const unsigned n = ctx_count[c];
+      nb = logs[c];
+      val = n ? ((unsigned)seg_end[seg_base[c] + (n + S - 1) / S - 1] & ((1u << nb) - 1u)) : 0u;
+    } else { val = 1u; nb = 1u; }  // end mark
+    const unsigned off = sh + log_prefix[c];  // log_prefix[B] = sum of logs
+    const unsigned long long field = (unsigned long long)val << (off & 31u);
+    atomicOr(&words[off >> 5], (uint32_t)field);
+    if ((off & 31u) + nb > 32u) atomicOr(&words[(off >> 5) + 1], (uint32_t)(field >> 32));
+  }
+  __syncthreads();
+  const unsigned long long gw0 = p0 >> 5;
+  const unsigned nw = (sh + log_prefix[B] + 1u + 31u) >> 5;
+  for (unsigned i = threadIdx.x; i < nw; i += blockDim.x) {
+    if (i == 0) atomicOr(&out[gw0], words[0]);
+    else out[gw0 + i] = words[i];
+  }
+}
+
+// ------------------------------------------------------------------ host orchestration
+template <class M>
+int encode_stream(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint32_t *rec_start, uint8_t *out_dev,
+                  size_t cap) {
+  hipStream_t st = ctx->stream;
+  EncScratch &sc = ctx->enc[M::STREAM];
+  const DevTables &tab = ctx->tab[M::STREAM];
+  constexpr unsigned B = M::B;
+  const unsigned n_sym = (unsigned)b->n_bases;
+  const unsigned R = (unsigned)b->n_recs;
+  const unsigned T = tile_size<M>();
+  const unsigned S = ctx->seg_len, W = ctx->warmup;
+  const unsigned n_tiles = (n_sym + T - 1) / T;
+  const unsigned n_groups = (n_tiles + GROUP_TILES - 1) / GROUP_TILES;
+  const unsigned n_ptiles = (n_sym + PACK_TILE - 1) / PACK_TILE;
+  const size_t padded = (size_t)n_sym + (size_t)CTX_PAD * B + 64;
+  const size_t max_segs = (size_t)n_sym / S + B + 1;
+  const unsigned max_items = (unsigned)((size_t)n_sym / ((size_t)S * 64) + B + 1);
+  StreamResult *res = &b->result->s[M::STREAM];
+
+  int rc;
+  if ((rc = sc.slot_of.reserve((size_t)n_sym * 4))) return rc;
+  if ((rc = sc.sorted_sym.reserve(padded))) return rc;
+  if ((rc = sc.out16.reserve(padded * 2))) return rc;
+  if ((rc = sc.tile_hist.reserve((size_t)n_tiles * B * 4))) return rc;
+  if ((rc = sc.tile_base.reserve((size_t)n_tiles * B * 4))) return rc;
+  if ((rc = sc.group_sum.reserve((size_t)n_groups * B * 4))) return rc;
+  if ((rc = sc.ctx_arrays.reserve((size_t)(4 * B + 3) * 4))) return rc;
+  if ((rc = sc.seg_state.reserve(max_segs * 2 * 2))) return rc;
+  if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
+  if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
+
+  uint32_t *arrays = sc.ctx_arrays.as<uint32_t>();
+  uint16_t *spec_start = sc.seg_state.as<uint16_t>();
+  uint16_t *seg_end = spec_start + max_segs;
+  const unsigned lds_ct = (1u + (1u << (tab.max_log - 1)) + 2u * M::A) * 4u;
+
+  hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R,
+                     n_sym, T, sc.tile_hist.as<uint32_t>(), res);
+  fq_timer_mark(ctx, M::STREAM ? "qual.tile_hist" : "seq.tile_hist");
+  hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
+                     sc.tile_hist.as<uint32_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
+  hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, sc.group_sum.as<uint32_t>(), n_groups,
+                     B, S, arrays);
+  hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
+                     sc.tile_hist.as<uint32_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B,
+                     sc.tile_base.as<uint32_t>());
+  fq_timer_mark(ctx, M::STREAM ? "qual.layout" : "seq.layout");
+  hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, b->raw, b->recs, rec_start, R,
+                     n_sym, T, sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
+                     sc.slot_of.as<uint32_t>());
+  fq_timer_mark(ctx, M::STREAM ? "qual.scatter" : "seq.scatter");
+  hipLaunchKernelGGL(k_chains<M>, dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                     sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, spec_start, seg_end, S, W);
+  fq_timer_mark(ctx, M::STREAM ? "qual.chains" : "seq.chains");
+  hipLaunchKernelGGL(k_fixup<M>, dim3(B), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                     sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, spec_start, seg_end, S, res);
+  fq_timer_mark(ctx, M::STREAM ? "qual.fixup" : "seq.fixup");
+  hipLaunchKernelGGL(k_bitcount, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
+                     sc.out16.as<uint16_t>(), n_sym, sc.tile_bits.as<uint32_t>());
+  fq_timer_mark(ctx, M::STREAM ? "qual.bitcount" : "seq.bitcount");
+  if ((rc = fq_scan_u32_to_u64(st, sc.tile_bits.as<uint32_t>(), n_ptiles,
+                               sc.tile_bit_base.as<unsigned long long>(), sc.scan_tmp)))
+    return rc;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1), 0, st, sc.tile_bit_base.as<unsigned long long>(),
+                     n_ptiles, tab.log_prefix, B, (unsigned long long)cap, res);
+  hipLaunchKernelGGL(k_zero_bounds, dim3((n_ptiles + 256) / 256), dim3(256), 0, st,
+                     sc.tile_bit_base.as<unsigned long long>(), n_ptiles,
+                     reinterpret_cast<uint32_t *>(out_dev), res);
+  fq_timer_mark(ctx, M::STREAM ? "qual.bitscan" : "seq.bitscan");
+  hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
+                     sc.out16.as<uint16_t>(), n_sym, sc.tile_bit_base.as<unsigned long long>(),
+                     reinterpret_cast<uint32_t *>(out_dev), res);
+  fq_timer_mark(ctx, M::STREAM ? "qual.pack" : "seq.pack");
+  hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, seg_end, tab.logs,
+                     tab.log_prefix, S, reinterpret_cast<uint32_t *>(out_dev), res);
+  fq_timer_mark(ctx, M::STREAM ? "qual.epilogue" : "seq.epilogue");
+  FQ_HIP(hipGetLastError());
+  return FQGPU_OK;
+}
+
+}  // namespace
+
+int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
+  hipStream_t st = ctx->stream;
+  const unsigned R = (unsigned)b->n_recs;
+  if (R == 0 || b->n_bases == 0) return FQGPU_E_ARG;
+  int rc;
+  if ((rc = ctx->rec_start.reserve((size_t)(R + 1) * 4))) return rc;
+  if ((rc = ctx->n_cnt32.reserve((size_t)R * 4 * 2))) return rc;  // n_cnt32 | lens32
+  if ((rc = ctx->n_off.reserve((size_t)(R + 1) * 4))) return rc;
+  uint32_t *n_cnt32 = ctx->n_cnt32.as<uint32_t>();
+  uint32_t *lens32 = n_cnt32 + R;
+
+  fq_timer_begin(ctx);
+  FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), st));
+  const unsigned rec_blocks = (unsigned)min((size_t)(R + 3) / 4, (size_t)8192);
+  hipLaunchKernelGGL(k_readlens_ncount, dim3(rec_blocks), dim3(256), 0, st, b->raw, b->recs, R,
+                     b->readlens, b->n_count, n_cnt32, lens32);
+  if ((rc = fq_scan_u32_to_u32(st, lens32, R, ctx->rec_start.as<uint32_t>(), ctx->scan_tmp))) return rc;
+  if ((rc = fq_scan_u32_to_u32(st, n_cnt32, R, ctx->n_off.as<uint32_t>(), ctx->scan_tmp))) return rc;
+  hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, ctx->n_off.as<uint32_t>(), R, b->result);
+  fq_timer_mark(ctx, "records");
+
+  if ((rc = encode_stream<SeqModel>(ctx, b, ctx->rec_start.as<uint32_t>(), b->seq, b->seq_cap))) return rc;
+  if ((rc = encode_stream<QualModel>(ctx, b, ctx->rec_start.as<uint32_t>(), b->qual, b->qual_cap))) return rc;
+
+  // after both streams: the optional in-place N -> A must not race with their reads of raw
+  hipLaunchKernelGGL(k_npos, dim3(rec_blocks), dim3(256), 0, st, b->raw, b->recs, R,
+                     ctx->n_off.as<uint32_t>(), b->n_pos, (flags & FQGPU_F_WRITE_BACK_N) ? 1 : 0);
+  fq_timer_mark(ctx, "npos");
+  fq_timer_end(ctx);
+  FQ_HIP(hipGetLastError());
+  return FQGPU_OK;
+}

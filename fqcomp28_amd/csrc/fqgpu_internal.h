@@ -1,0 +1,238 @@
+// Internal declarations shared by the HIP translation units of libfqgpu.so.
+// gfx950 (MI355X, wave64) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/fqgpu.h"
+
+#define FQ_WAVE 64
+
+// ---------------------------------------------------------------- models
+// Context/symbol definition of the two streams (reference a2/a4 in SURVEY.md 8(a)).
+struct SeqModel {
+  static constexpr int B = FQGPU_SEQ_MODELS;  // contexts
+  static constexpr int A = FQGPU_SEQ_ALPHA;   // alphabet
+  static constexpr int KEYBITS = 8;
+  static constexpr int STREAM = 0;
+};
+struct QualModel {
+  static constexpr int B = FQGPU_QUAL_MODELS;
+  static constexpr int A = FQGPU_QUAL_ALPHA;
+  static constexpr int KEYBITS = 13;
+  static constexpr int STREAM = 1;
+};
+
+// Device-side tables of one stream, built once per handle.
+struct DevTables {
+  int16_t *norm = nullptr;      // [B][A]
+  uint32_t *logs = nullptr;     // [B]
+  uint32_t *log_prefix = nullptr;  // [B+1] exclusive prefix of logs (bit offsets of the state flush)
+  uint32_t *ct = nullptr;       // CTable pool, zstd word layout per context
+  uint32_t *ct_off = nullptr;   // [B] word offset of each CTable
+  uint32_t *dt = nullptr;       // DTable pool, zstd word layout per context
+  uint32_t *dt_off = nullptr;   // [B]
+  uint32_t max_log = 0;
+  size_t ct_words = 0, dt_words = 0;
+};
+
+// Result block of one (block, stream) coding job, in device memory.
+struct StreamResult {
+  unsigned long long total_bits;  // payload bits (before state flush)
+  unsigned long long len;         // bytes of the finished stream
+  unsigned int overflow;          // reference capacity rule violated
+  unsigned int bad_symbol;        // quality above Q63 seen
+  unsigned int refixed;           // segments the fix-up pass had to re-run
+  unsigned int corrupt;           // decode: bad end mark / bits left over
+};
+
+struct BlockResult {
+  StreamResult s[2];
+  unsigned long long n_pos_len;  // number of u16 entries in n_pos
+};
+
+// ---------------------------------------------------------------- helpers
+#define FQ_HIP(call)                                                 \
+  do {                                                               \
+    hipError_t e_ = (call);                                          \
+    if (e_ != hipSuccess) return fq_hip_error(e_, __FILE__, __LINE__); \
+  } while (0)
+
+int fq_hip_error(hipError_t e, const char *file, int line);
+
+template <class T> static inline T *fq_dev_alloc(size_t n) {
+  void *p = nullptr;
+  if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+  return reinterpret_cast<T *>(p);
+}
+
+// Growable device buffer (never shrinks): the per-handle scratch.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return FQGPU_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return FQGPU_E_NOMEM; }
+    cap = want;
+    return FQGPU_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct KernelTimer;  // api.cpp
+
+// Scratch of the encode pipeline for one stream.
+struct EncScratch {
+  DevBuf slot_of;     // u32 [M]   sorted position of every symbol (encode order)
+  DevBuf sorted_sym;  // u8  [M+pad]
+  DevBuf out16;       // u16 [M+pad] (nb<<12 | bits) at sorted position
+  DevBuf tile_hist;   // u32 [tiles][B]
+  DevBuf tile_base;   // u32 [tiles][B]
+  DevBuf group_sum;   // u32 [groups][B]
+  DevBuf ctx_arrays;  // ctx_count[B], ctx_start[B+1], seg_base[B+1], item_base[B+1]
+  DevBuf seg_state;   // u16 spec_start[nsegmax], u16 seg_end[nsegmax]
+  DevBuf tile_bits;   // u32 [ptiles]
+  DevBuf tile_bit_base;  // u64 [ptiles+1]
+  DevBuf scan_tmp;    // u64 chunk sums for the scans
+};
+
+struct fqgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevTables tab[2];
+  unsigned seg_len = 512, warmup = 64;
+  // scratch shared by both streams of a block
+  DevBuf rec_start;   // u32 [R+1] first encode index of each record
+  DevBuf n_cnt32;     // u32 [R]
+  DevBuf n_off;       // u32 [R+1]
+  DevBuf scan_tmp;
+  EncScratch enc[2];
+  DevBuf dec_desc;    // decode job descriptors
+  DevBuf tmp_result;  // BlockResult for host-pointer calls
+  KernelTimer *timer = nullptr;
+};
+
+struct fqgpu_dblock {
+  int device = 0;
+  uint8_t *raw = nullptr;
+  size_t raw_len = 0;
+  fqgpu_rec *recs = nullptr;
+  size_t n_recs = 0;
+  size_t n_bases = 0;
+  uint8_t *seq = nullptr;  size_t seq_cap = 0;
+  uint8_t *qual = nullptr; size_t qual_cap = 0;
+  uint16_t *readlens = nullptr, *n_count = nullptr, *n_pos = nullptr;
+  size_t n_pos_cap = 0;
+  BlockResult *result = nullptr;  // device
+  BlockResult host_result;        // filled by fqgpu_sync-ing calls
+  size_t seq_len = 0, qual_len = 0, n_pos_len = 0;  // stream sizes used by decode
+  int last_op = 0;  // 1 = encode, 2 = decode: which fields of the result block are meaningful
+};
+
+// ---------------------------------------------------------------- launches (encode.hip / decode.hip / tables.hip)
+int fq_build_freq_tables(int device, hipStream_t st, const uint8_t *raw_dev, const fqgpu_rec *recs_dev,
+                         size_t n_recs, uint32_t *seq_counts_dev, uint32_t *qual_counts_dev);
+int fq_normalize_counts(hipStream_t st, const uint32_t *counts_dev, int n_models, int alpha,
+                        int16_t *norm_dev, uint32_t *logs_dev, uint32_t *max_log_dev, uint32_t *err_dev);
+int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint32_t *err_dev);
+
+int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags);
+int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks);
+int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);
+
+// generic exclusive scans (scan.hip): out has n+1 entries, out[n] = total
+int fq_scan_u32_to_u32(hipStream_t st, const uint32_t *in, size_t n, uint32_t *out, DevBuf &tmp);
+int fq_scan_u32_to_u64(hipStream_t st, const uint32_t *in, size_t n, unsigned long long *out, DevBuf &tmp);
+
+// kernel timing hooks (api.cpp)
+void fq_timer_begin(fqgpu_ctx *ctx);
+void fq_timer_mark(fqgpu_ctx *ctx, const char *name);  // call after each launch
+void fq_timer_end(fqgpu_ctx *ctx);
+
+// ---------------------------------------------------------------- device helpers
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ unsigned fq_lane() { return threadIdx.x & 63u; }
+
+// number of set bits of m below the calling lane
+__device__ __forceinline__ unsigned fq_mbcnt(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// lanes of the wave holding the same key as the caller (among valid lanes)
+template <int BITS>
+__device__ __forceinline__ unsigned long long fq_match_any(unsigned key, bool valid) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < BITS; b++) {
+    const bool bit = (key >> b) & 1u;
+    const unsigned long long bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+// A0 C1 G2 T3, everything else (N, which the coder treats as A: src/fse_sequence.cpp:44) -> 0
+__device__ __forceinline__ unsigned fq_base_code(unsigned c) {
+  return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+}
+
+// FSE_Quality::calcContext (src/fse_quality.h:40-44)
+__device__ __forceinline__ unsigned fq_qual_ctx(unsigned q, unsigned q1, unsigned q2) {
+  unsigned ctx = ((((q1 > q2) ? q1 : q2) << 6) + q) & 0xFFFu;
+  ctx += (unsigned)(q1 == q2) << 12;
+  return ctx;
+}
+
+// largest r in [lo, hi] with rec_start[r] <= e
+__device__ __forceinline__ unsigned fq_locate(const uint32_t *__restrict__ rec_start, unsigned lo,
+                                              unsigned hi, unsigned e) {
+  while (lo < hi) {
+    const unsigned mid = lo + ((hi - lo + 1) >> 1);
+    if (rec_start[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// (context, symbol) of position p of a record; encode-side definition
+// (SequenceEncoder::encodeRecord src/fse_sequence.cpp:53-112: context = the four
+// bases in front of p, nearest in bits 7:6, virtual T,C,C,T = 0xD7 before the read)
+__device__ __forceinline__ void fq_seq_sym_ctx(const uint8_t *__restrict__ s, unsigned p,
+                                               unsigned &ctx, unsigned &sym) {
+  sym = fq_base_code(s[p]);
+  unsigned c = 0;
+#pragma unroll
+  for (int k = 1; k <= 4; k++) {
+    const int q = (int)p - k;
+    const unsigned code = q >= 0 ? fq_base_code(s[q]) : ((0xD7u >> (2 * (4 + q))) & 3u);
+    c |= code << (2 * (4 - k));
+  }
+  ctx = c;
+}
+
+// QualityEncoder::encodeRecord src/fse_quality.cpp:5-53 (L >= 3): context of p is
+// calcContext(Q[p-1], Q[p-2], Q[p-3]) with zeros in front of the read
+__device__ __forceinline__ void fq_qual_sym_ctx(const uint8_t *__restrict__ qs, unsigned p,
+                                                unsigned &ctx, unsigned &sym) {
+  sym = (unsigned)qs[p] - 33u;
+  const unsigned q = p >= 1 ? (unsigned)qs[p - 1] - 33u : 0u;
+  const unsigned q1 = p >= 2 ? (unsigned)qs[p - 2] - 33u : 0u;
+  const unsigned q2 = p >= 3 ? (unsigned)qs[p - 3] - 33u : 0u;
+  ctx = fq_qual_ctx(q & 63u, q1 & 63u, q2 & 63u);
+}
+
+template <class M>
+__device__ __forceinline__ void fq_sym_ctx(const uint8_t *__restrict__ raw, const fqgpu_rec &rec,
+                                           unsigned p, unsigned &ctx, unsigned &sym) {
+  if (M::STREAM == 0) fq_seq_sym_ctx(raw + rec.seq_off, p, ctx, sym);
+  else fq_qual_sym_ctx(raw + rec.qual_off, p, ctx, sym);
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,179 @@
+/*
+ * fqgpu.h -- C ABI of the MI355X-native FASTQ block entropy coder.
+ *
+ * This is the drop-in boundary for ONE hot path of iam28th/fqcomp28: the
+ * per-block context-modelled FSE coding of bases and quality scores.  The
+ * reference has no FFI layer; the seam is its block codec
+ *     CompressionWorkspace::encodeChunk(FastqChunk&, CompressedBuffersDst&)    src/workspace.h:69
+ *     DecompressionWorkspace::decodeChunk(FastqChunk&, CompressedBuffersSrc&)  src/workspace.h:112
+ *     FSE_{Sequence,Quality}::calculateFreqTable(const FastqChunk&)            src/fse_sequence.h:72, src/fse_quality.h:50
+ * and each entry point below names the reference code it replaces.  The C++
+ * shim that keeps the reference's Workspace/CompressedBuffers surface on top of
+ * this ABI is fqcomp28_amd/csrc/workspace.hpp; INTEGRATION.md shows the patch a
+ * maintainer of the reference would apply.
+ *
+ * Conventions: plain pointers and sizes, little-endian integers, no exceptions
+ * across the boundary; every function returns FQGPU_OK (0) or a negative
+ * FQGPU_E_* code.  Pointers are HOST memory unless the name ends in _dev.
+ * A handle is not re-entrant (like a reference Workspace, src/process.cpp:49-54);
+ * different handles are independent and may live on different GPUs.
+ * There is NO CPU fallback: every call fails with FQGPU_E_NO_DEVICE without a GPU.
+ */
+#ifndef FQGPU_H
+#define FQGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQGPU_SEQ_MODELS 256   /* FSE_Sequence::N_MODELS,  src/fse_sequence.h:66 */
+#define FQGPU_SEQ_ALPHA 4      /* FSE_Sequence::ALPHABET_SIZE, :36 */
+#define FQGPU_QUAL_MODELS 8192 /* FSE_Quality::N_MODELS,   src/fse_quality.h:31 */
+#define FQGPU_QUAL_ALPHA 64    /* FSE_Quality::ALPHABET_SIZE, :22 */
+#define FQGPU_SEQ_FT_BYTES 3076     /* sizeof(FreqTable<256,4>),   src/fse_common.hpp:147-174 */
+#define FQGPU_QUAL_FT_BYTES 1081348 /* sizeof(FreqTable<8192,64>) */
+
+enum {
+  FQGPU_OK = 0,
+  FQGPU_E_OVERFLOW = -1,   /* stream does not fit the reference capacity rule: endChunk()==0, src/fse_common.hpp:85-90 */
+  FQGPU_E_SHORT_READ = -2, /* a read shorter than 3: undefined in the reference (src/fse_quality.cpp:11-12) */
+  FQGPU_E_CORRUPT = -3,    /* decode: end mark missing / stream not fully consumed (BIT_endOfDStream, src/fse_common.hpp:141) */
+  FQGPU_E_ARG = -4,        /* bad argument, quality above Q63 (src/fse_quality.cpp:88 throws), bad table */
+  FQGPU_E_NO_DEVICE = -5,  /* no usable GPU / HIP runtime error: the product path has no CPU fallback */
+  FQGPU_E_NOMEM = -6,
+  FQGPU_E_HIP = -7
+};
+
+/* FastqRecord reduced to what this path needs (src/defs.h:22-32): byte offsets
+ * of the sequence and quality lines inside the raw block, and their length. */
+typedef struct {
+  uint32_t seq_off, qual_off, len;
+} fqgpu_rec;
+
+typedef struct fqgpu_ctx fqgpu_ctx;
+
+/* ---- lifecycle ------------------------------------------------------- */
+int fqgpu_device_count(void);
+const char *fqgpu_strerror(int code);
+const char *fqgpu_version(void);
+
+/* Workspace::compressBoundSequence / compressBoundQuality (src/workspace.h:21-35) */
+size_t fqgpu_bound_seq(size_t total_bases);
+size_t fqgpu_bound_qual(size_t total_bases);
+
+/* ---- dataset analysis (replaces FSE_Sequence::calculateFreqTable
+ * src/fse_sequence.cpp:145-169, FSE_Quality::calculateFreqTable
+ * src/fse_quality.cpp:69-97 and makeNormalizedFreqTable src/fse_common.hpp:179-200).
+ * Histograms the parsed sample block on the GPU and normalises every context
+ * into the reference's FreqTable POD layout (what DatasetMeta dumps into the
+ * archive, src/prepare.cpp:18-20).  seq_counts_out / qual_counts_out are
+ * optional (NULL) dumps of the raw u32 counts [256][4] / [8192][64]. */
+int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
+                      size_t n_recs, void *seq_ft_out, void *qual_ft_out,
+                      uint32_t *seq_counts_out, uint32_t *qual_counts_out);
+/* Same, from raw counts already on the host (normalisation only, on the GPU). */
+int fqgpu_tables_from_counts(int device, const uint32_t *seq_counts, const uint32_t *qual_counts,
+                             void *seq_ft_out, void *qual_ft_out);
+
+/* ---- workspace (replaces the SequenceEncoder/QualityEncoder/…Decoder ctors,
+ * src/fse_common.hpp:46-71,107-127: 256 + 8192 CTables and DTables are built on
+ * the device from the FreqTable PODs).  One per (host thread, GPU). */
+int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual_ft, fqgpu_ctx **out);
+void fqgpu_ctx_destroy(fqgpu_ctx *ctx);
+/* Tuning knobs of the speculative state-chain kernels (segment length and
+ * warm-up, in symbols; 0 keeps the default).  Results never depend on them. */
+int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned warmup);
+/* Test hook: copies the device-built tables of one context out in zstd's memory
+ * layout (FSE_CTable / FSE_DTable u32 words).  stream: 0 = sequence, 1 = quality. */
+int fqgpu_ctx_dump_tables(fqgpu_ctx *ctx, int stream, unsigned model, uint32_t *ctable_out,
+                          size_t ctable_cap_words, uint32_t *dtable_out, size_t dtable_cap_words);
+
+/* ---- block encode (replaces the seq/qual part of
+ * CompressionWorkspace::encodeChunk, src/workspace.cpp:14-45, i.e.
+ * prepareBuffersForEncoding :159-174, startChunk, the per-record
+ * replaceAndEncodeNs + SequenceEncoder::encodeRecord + QualityEncoder::encodeRecord
+ * loop :25-31, and endChunk).  seq_out/qual_out receive bytes bit-identical to
+ * cbs.seq / cbs.qual; readlens_out (n_recs u16) = cbs.readlens; n_count_out
+ * (n_recs u16) and n_pos_out (one u16 per N) are what a FRESH CompressedBuffersDst
+ * would hold.  seq_cap/qual_cap are the reference capacities (fqgpu_bound_*):
+ * exceeding them returns FQGPU_E_OVERFLOW instead of the reference's silent 0.
+ * flags: FQGPU_F_WRITE_BACK_N also rewrites N -> A inside `raw` like the reference. */
+#define FQGPU_F_WRITE_BACK_N 1u
+int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
+                       size_t n_recs, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
+                       uint8_t *qual_out, size_t qual_cap, size_t *qual_len,
+                       uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
+                       size_t n_pos_cap, size_t *n_pos_len, unsigned flags);
+
+/* ---- block decode (replaces the second pass of
+ * DecompressionWorkspace::decodeChunk, src/workspace.cpp:84-87:
+ * SequenceDecoder::decodeRecord src/fse_sequence.cpp:114-143 and
+ * QualityDecoder::decodeRecord src/fse_quality.cpp:55-67, records last->first).
+ * raw_out is the block skeleton laid out by the first pass (:62-80); only the
+ * sequence and quality line bytes are written. */
+int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual,
+                       size_t qual_len, const uint16_t *n_count, size_t n_count_len,
+                       const uint16_t *n_pos, size_t n_pos_len, const fqgpu_rec *recs,
+                       size_t n_recs, uint8_t *raw_out, size_t raw_len);
+
+/* ---- device-resident block farm ---------------------------------------
+ * Blocks stay in HBM: a "dblock" owns device copies of one raw block, its
+ * record table and its coded streams.  Used by the pipeline shim to overlap
+ * H2D/D2H with coding, by bench.py (timed region starts with inputs resident)
+ * and by the many-blocks decode path, where all blocks of a batch are decoded
+ * by ONE launch (the format gives a decoder no parallelism inside a stream:
+ * SURVEY.md 7.3). */
+typedef struct fqgpu_dblock fqgpu_dblock;
+int fqgpu_dblock_create(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
+                        size_t n_recs, fqgpu_dblock **out);
+void fqgpu_dblock_destroy(fqgpu_dblock *b);
+/* asynchronous on the handle's stream; sizes are valid after fqgpu_sync() */
+int fqgpu_dblock_encode(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags);
+/* wipes the sequence/quality bytes of the device raw block (decode target) */
+int fqgpu_dblock_wipe(fqgpu_ctx *ctx, fqgpu_dblock *b);
+/* decodes every block of the batch from its own device-resident streams */
+int fqgpu_dblocks_decode(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks);
+int fqgpu_sync(fqgpu_ctx *ctx);
+/* status/sizes of the last encode/decode of this block (after fqgpu_sync) */
+int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_t *qual_len,
+                        size_t *n_pos_len, size_t *n_bases);
+/* copies results to the host (synchronous); any pointer may be NULL */
+int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t *seq_out, uint8_t *qual_out,
+                       uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
+                       uint8_t *raw_out);
+/* replaces the block's coded streams with host data (decode of foreign archives) */
+int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint8_t *seq, size_t seq_len,
+                              const uint8_t *qual, size_t qual_len, const uint16_t *n_count,
+                              const uint16_t *n_pos, size_t n_pos_len);
+
+/* Device time (ms) spent between the start and the end of the last
+ * fqgpu_dblock_encode / fqgpu_dblocks_decode on this handle, measured with HIP
+ * events on the handle's own stream; per-kernel times for the roofline line. */
+typedef struct {
+  float total_ms;
+  float kernel_ms[24];
+  const char *kernel_name[24];
+  int n_kernels;
+} fqgpu_timing;
+int fqgpu_ctx_enable_timing(fqgpu_ctx *ctx, int on);
+int fqgpu_ctx_last_timing(fqgpu_ctx *ctx, fqgpu_timing *out);
+
+/* ---- host helpers of the path's callers (not GPU code) ------------------
+ * Minimal 4-line FASTQ parser with the reference's semantics
+ * (FastqReader::parseRecords, src/fastq_io.cpp:67-125): returns the number of
+ * complete records found (writes at most cap of them) or a negative error. */
+long fqgpu_parse_fastq(const uint8_t *raw, size_t len, fqgpu_rec *recs, size_t cap);
+/* Deterministic synthetic FASTQ for the BASELINE.json configs:
+ * mode 1: 150 bp, N w.p. 0.001, all quals 'I'; mode 2: 150 bp uniform ACGT,
+ * Phred ~ round(N(34,5)) clipped to [2,41]; mode 4: length U[50,300], N w.p. 0.01
+ * with quality '#'.  Writes whole records only; returns bytes written. */
+size_t fqgpu_synth_fastq(uint8_t *dst, size_t cap, int mode, uint64_t seed, uint64_t first_read_id,
+                         uint64_t *n_reads_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
