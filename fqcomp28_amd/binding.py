@@ -81,6 +81,7 @@ _PROTOS = {
     "fqgpu_sync": (C.c_int, [C.c_void_p]),
     "fqgpu_dblock_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "fqgpu_dblock_refixed": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "fqgpu_dblock_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "fqgpu_dblock_load_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -199,6 +200,11 @@ class DBlock:
         a, b, c, d = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
         rc = lib().fqgpu_dblock_status(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         return rc, dict(seq_len=a.value, qual_len=b.value, n_pos_len=c.value, n_bases=d.value)
+
+    def refixed(self):
+        a, b = C.c_uint(), C.c_uint()
+        _check(lib().fqgpu_dblock_refixed(self.h, C.byref(a), C.byref(b)), "dblock_refixed")
+        return a.value, b.value
 
     def fetch(self, raw=False):
         rc, st = self.status()

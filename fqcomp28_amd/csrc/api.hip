@@ -446,6 +446,16 @@ extern "C" int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_
   return rc;
 }
 
+extern "C" int fqgpu_dblock_refixed(const fqgpu_dblock *b, unsigned *seq_segments, unsigned *qual_segments) {
+  if (!b) return FQGPU_E_ARG;
+  (void)hipSetDevice(b->device);
+  BlockResult tmp;
+  FQ_HIP(hipMemcpy(&tmp, b->result, sizeof(tmp), hipMemcpyDeviceToHost));
+  if (seq_segments) *seq_segments = tmp.s[0].refixed;
+  if (qual_segments) *qual_segments = tmp.s[1].refixed;
+  return FQGPU_OK;
+}
+
 extern "C" int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t *seq_out, uint8_t *qual_out,
                                   uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
                                   uint8_t *raw_out) {

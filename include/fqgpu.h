@@ -140,6 +140,9 @@ int fqgpu_sync(fqgpu_ctx *ctx);
 /* status/sizes of the last encode/decode of this block (after fqgpu_sync) */
 int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_t *qual_len,
                         size_t *n_pos_len, size_t *n_bases);
+/* diagnostics of the last encode (after fqgpu_sync): how many chain segments per
+ * stream the verification pass found mis-speculated and re-ran serially */
+int fqgpu_dblock_refixed(const fqgpu_dblock *b, unsigned *seq_segments, unsigned *qual_segments);
 /* copies results to the host (synchronous); any pointer may be NULL */
 int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t *seq_out, uint8_t *qual_out,
                        uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,

@@ -1,0 +1,339 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of include/fqgpu.h) against the
+CPU oracle on the same inputs, against the committed golden vectors, and -- at BASELINE.json's
+full size -- through the encode -> wipe -> decode round trip.  Integer/byte work: bit-exact."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ["SRR065390_sub_1", "without_ns", "SRR065390_sub_2", "SRR065390_1_first5"]
+
+
+def sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fqcomp28_amd as F
+    assert F.device_count() >= 1, "no GPU visible: the product path has no CPU fallback"
+    return F
+
+
+@pytest.fixture(scope="module")
+def expected(golden_dir):
+    with open(os.path.join(golden_dir, "expected.json")) as fh:
+        return json.load(fh)
+
+
+def assert_same_encoding(g, e):
+    assert g["rc"] == 0 and e["rc"] == 0
+    for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+        assert np.array_equal(np.asarray(g[k]), np.asarray(e[k])), k
+
+
+# ---------------------------------------------------------------- reference fixtures
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_tables_and_streams(F, name, golden_dir, expected):
+    raw, recs = O.load_fastq(os.path.join(golden_dir, name + ".fastq"))
+    assert np.array_equal(F.parse_fastq(raw), recs)
+    sc, qc, sft, qft = O.freq_tables(raw, recs)
+    gs, gq, gsc, gqc = F.freq_tables(raw, recs, want_counts=True)
+    # calculateFreqTable + makeNormalizedFreqTable (a3/a4/a5)
+    assert np.array_equal(gsc, sc) and np.array_equal(gqc, qc)
+    assert gs.tobytes() == sft.tobytes() and gq.tobytes() == qft.tobytes()
+    x = expected[name]
+    assert sha(gs) == x["seq_ft_sha1"] and sha(gq) == x["qual_ft_sha1"]
+    # encodeChunk seq/qual part (a7-a13) from GPU-built tables, against oracle AND golden
+    ctx = F.Context(gs, gq)
+    g = ctx.encode_block(raw, recs, flags=1)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    assert_same_encoding(g, e)
+    assert np.array_equal(g["raw_after"], e["raw_after"])  # N -> A written back
+    assert (len(g["seq"]), sha(g["seq"])) == (x["seq_len"], x["seq_sha1"])
+    assert (len(g["qual"]), sha(g["qual"])) == (x["qual_len"], x["qual_sha1"])
+    assert sha(g["n_count"]) == x["n_count_sha1"] and sha(g["n_pos"]) == x["n_pos_sha1"]
+    # decodeChunk second pass (a14-a17): GPU decodes the ORACLE's streams
+    rc, out = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
+def test_first5_golden_bytes(F, golden_dir):
+    name = "SRR065390_1_first5"
+    raw, recs = O.load_fastq(os.path.join(golden_dir, name + ".fastq"))
+    sft, qft = F.freq_tables(raw, recs)
+    g = F.Context(sft, qft).encode_block(raw, recs)
+    assert np.array_equal(g["seq"], np.fromfile(os.path.join(golden_dir, name + ".seq.bin"), dtype=np.uint8))
+    assert np.array_equal(g["qual"], np.fromfile(os.path.join(golden_dir, name + ".qual.bin"), dtype=np.uint8))
+    assert np.array_equal(g["n_pos"], np.fromfile(os.path.join(golden_dir, name + ".n_pos.bin"), dtype=np.uint16))
+    assert sft.tobytes() == open(os.path.join(golden_dir, name + ".seq_ft.bin"), "rb").read()
+
+
+def test_device_tables_match_oracle_word_for_word(F, golden_dir):
+    """FSE_buildCTable_wksp / FSE_buildDTable_wksp for every context (a6, a14)."""
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_1.fastq"))
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    ctx = F.Context(sft, qft)
+    L = O.lib()
+    for stream, ft, alpha, models in ((0, sft, 4, range(256)), (1, qft, 64, range(0, 8192, 7))):
+        for m in models:
+            ct, dt = ctx.dump_tables(stream, m)
+            log = int(ft["logs"][0][m])
+            oc = np.zeros(L.fo_ctable_words(log, alpha - 1), dtype=np.uint32)
+            od = np.zeros(L.fo_dtable_words(log), dtype=np.uint32)
+            norm = np.ascontiguousarray(ft["norm"][0][m])
+            assert L.fo_build_ctable(O.ptr(oc), O.ptr(norm), alpha - 1, log) == 0
+            assert L.fo_build_dtable(O.ptr(od), O.ptr(norm), alpha - 1, log) == 0
+            assert np.array_equal(ct, oc), (stream, m)
+            assert np.array_equal(dt, od), (stream, m)
+    ctx.close()
+
+
+def test_tables_from_counts_normalisation_corner_cases(F):
+    """Count vectors that hit the low-probability (-1), the rounding and the normalizeM2 paths."""
+    rng = np.random.default_rng(5)
+    sc = 1 + rng.integers(0, 3000, (256, 4)).astype(np.uint32)
+    sc[3] = [1, 1, 1, 1]
+    sc[4] = [1, 1, 1, 900000]
+    qc = np.ones((8192, 64), dtype=np.uint32)
+    for c in range(0, 8192, 3):
+        k = rng.integers(2, 64)
+        qc[c, :k] += rng.integers(0, 60, k).astype(np.uint32)
+        qc[c, rng.integers(0, 64)] += np.uint32(rng.integers(0, 5000))
+    for c in range(1, 8192, 97):
+        qc[c] = 1 + (rng.pareto(0.6, 64) * 30).astype(np.uint32)
+    L = O.lib()
+    osft = np.zeros(1, dtype=O.SEQ_FT_DTYPE)
+    oqft = np.zeros(1, dtype=O.QUAL_FT_DTYPE)
+    assert L.fqo_seq_ft_from_counts(O.ptr(sc), O.ptr(osft)) == 0
+    assert L.fqo_qual_ft_from_counts(O.ptr(qc), O.ptr(oqft)) == 0
+    gs, gq = F.tables_from_counts(sc, qc)
+    assert gs.tobytes() == osft.tobytes()
+    assert gq.tobytes() == oqft.tobytes()
+    # and the tables built from them (covers logs 5..11 and many -1 symbols)
+    ctx = F.Context(gs, gq)
+    for m in range(0, 8192, 11):
+        ct, dt = ctx.dump_tables(1, m)
+        log = int(oqft["logs"][0][m])
+        oc = np.zeros(L.fo_ctable_words(log, 63), dtype=np.uint32)
+        od = np.zeros(L.fo_dtable_words(log), dtype=np.uint32)
+        norm = np.ascontiguousarray(oqft["norm"][0][m])
+        L.fo_build_ctable(O.ptr(oc), O.ptr(norm), 63, log)
+        L.fo_build_dtable(O.ptr(od), O.ptr(norm), 63, log)
+        assert np.array_equal(ct, oc) and np.array_equal(dt, od), m
+    ctx.close()
+
+
+# ---------------------------------------------------------------- speculation is invisible in the output
+@pytest.mark.parametrize("seg,warm", [(4, 0xFFFFFFFF), (16, 0xFFFFFFFF), (64, 8), (4096, 64)])
+def test_chain_parameters_never_change_the_bits(F, golden_dir, seg, warm):
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_2.fastq"))
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    ctx.set_chain_params(seg, warm)
+    b = ctx.dblock(raw, recs)
+    b.encode()
+    ctx.sync()
+    g = b.fetch()
+    for k in ("seq", "qual", "n_count", "n_pos"):
+        assert np.array_equal(g[k], e[k]), k
+    rs, rq = b.refixed()
+    if warm == 0xFFFFFFFF:  # no warm-up at all: the verification pass must have had work to do
+        assert rs + rq > 0
+    b.close()
+    ctx.close()
+
+
+# ---------------------------------------------------------------- BASELINE.json configurations (reduced sizes vs oracle)
+def _synth(F, mode, size, seed=28):
+    raw, n = F.synth_fastq(size, mode, seed=seed)
+    recs = F.parse_fastq(raw)
+    assert len(recs) == n
+    return raw, recs
+
+
+def test_config1_uniform_q40_degenerate_context(F):
+    """configs[0]: 10k x 150 bp, all quals 'I' (one context holds ~98% of the symbols and its
+    state chain never forgets: worst case for the speculation)."""
+    raw, recs = _synth(F, 1, 10000 * 335 + 4096)
+    raw = raw[: recs[9999]["qual_off"] + 151] if len(recs) > 10000 else raw
+    recs = F.parse_fastq(raw)
+    assert len(recs) == 10000
+    sft, qft = F.freq_tables(raw, recs)
+    _, _, osft, oqft = O.freq_tables(raw, recs)
+    assert sft.tobytes() == osft.tobytes() and qft.tobytes() == oqft.tobytes()
+    e = O.OracleCtx(osft, oqft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    g = ctx.encode_block(raw, recs)
+    assert_same_encoding(g, e)
+    assert len(g["n_pos"]) > 0
+    rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode,size", [(2, 12 << 20), (4, 12 << 20)])
+def test_config2_and_config4_blocks_match_oracle(F, mode, size):
+    """configs[1]/[3] at 12 MiB: tables from a different sample (first 4 MiB) than the coded block."""
+    raw, recs = _synth(F, mode, size)
+    sample_recs = recs[recs["qual_off"] < (4 << 20)]
+    sft, qft = F.freq_tables(raw, sample_recs)
+    _, _, osft, oqft = O.freq_tables(raw, sample_recs)
+    assert sft.tobytes() == osft.tobytes() and qft.tobytes() == oqft.tobytes()
+    e = O.OracleCtx(osft, oqft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    g = ctx.encode_block(raw, recs, flags=1)
+    assert_same_encoding(g, e)
+    assert np.array_equal(g["raw_after"], e["raw_after"])
+    if mode == 4:
+        assert len(g["n_pos"]) > 10000 and recs["len"].min() < 60 and recs["len"].max() > 290
+    rc, out = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
+def test_config5_decode_batch_of_oracle_archive_blocks(F):
+    """configs[4] in small: blocks coded by the ORACLE (the reference binary cannot be built) are
+    decoded by one GPU launch over the whole batch; every block restores byte-equal."""
+    raw, recs = _synth(F, 4, 6 << 20, seed=5)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    octx = O.OracleCtx(sft, qft)
+    ctx = F.Context(sft, qft)
+    # cut into 12 blocks at record boundaries
+    cuts = np.linspace(0, len(recs), 13).astype(int)
+    blocks, originals = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo = 0 if a == 0 else int(recs[a - 1]["qual_off"] + recs[a - 1]["len"] + 1)
+        hi = int(recs[b - 1]["qual_off"] + recs[b - 1]["len"] + 1)
+        braw = raw[lo:hi]
+        brecs = recs[a:b].copy()
+        brecs["seq_off"] -= lo
+        brecs["qual_off"] -= lo
+        e = octx.encode(braw, brecs)
+        assert e["rc"] == 0
+        db = ctx.dblock(O.blank_skeleton(braw, brecs), brecs)
+        db.load_streams(e["seq"], e["qual"], e["n_count"], e["n_pos"])
+        blocks.append(db)
+        originals.append(braw)
+    ctx.decode_dblocks(blocks)
+    ctx.sync()
+    for db, braw in zip(blocks, originals):
+        rc, _ = db.status()
+        assert rc == 0
+        assert np.array_equal(db.fetch_raw(), braw)
+        db.close()
+    ctx.close()
+
+
+# ---------------------------------------------------------------- error behaviour
+def test_errors(F):
+    raw, recs = _synth(F, 2, 1 << 20)
+    sft, qft = F.freq_tables(raw, recs)
+    ctx = F.Context(sft, qft)
+    # capacity rule violated -> explicit error (the reference returns size 0 silently)
+    assert ctx.encode_block(raw, recs, seq_cap=4096)["rc"] == -1
+    assert ctx.encode_block(raw, recs, qual_cap=8192)["rc"] == -1
+    # read shorter than 3
+    short = np.frombuffer(b"@r\nAC\n+\nII\n@s\nACGT\n+\nIIII\n", dtype=np.uint8)
+    assert ctx.encode_block(short, F.parse_fastq(short))["rc"] == -2
+    # quality above Q63 ('a' = 97 > 96): calculateFreqTable throws in the reference
+    bad = np.frombuffer(b"@r\nACGTA\n+\nIIaII\n", dtype=np.uint8)
+    with pytest.raises(F.FqgpuError) as ei:
+        F.freq_tables(bad, F.parse_fastq(bad))
+    assert ei.value.code == -4
+    assert ctx.encode_block(bad, F.parse_fastq(bad))["rc"] == -4
+    # record table pointing outside the block
+    r2 = recs[:10].copy()
+    r2["qual_off"][3] = raw.size
+    assert ctx.encode_block(raw, r2)["rc"] == -4
+    # corrupt streams: end mark gone, truncated, bit flipped near the end
+    g = ctx.encode_block(raw, recs)
+    skel = O.blank_skeleton(raw, recs)
+    z = g["seq"].copy(); z[-1] = 0
+    assert ctx.decode_block(z, g["qual"], g["n_count"], g["n_pos"], recs, skel)[0] == -3
+    assert ctx.decode_block(g["seq"][:-5], g["qual"], g["n_count"], g["n_pos"], recs, skel)[0] == -3
+    q = g["qual"].copy(); q[-1] ^= (1 << (int(q[-1]).bit_length() - 1)) | (1 << int(q[-1]).bit_length() % 8)
+    assert ctx.decode_block(g["seq"], q, g["n_count"], g["n_pos"], recs, skel)[0] in (-3, 0) 
+    rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, skel)
+    assert rc == 0 and np.array_equal(out, raw)
+    # tables that do not sum to 2^log are refused
+    broken = sft.copy(); broken["norm"][0][7][0] += 1
+    with pytest.raises(F.FqgpuError):
+        F.Context(broken, qft)
+    ctx.close()
+
+
+def test_accumulated_n_buffers_decode_from_the_end(F, golden_dir):
+    """a reused CompressedBuffersDst carries the n_count/n_pos of earlier blocks in
+    front; the decoder pops from the END, so extra leading entries must not matter."""
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_1.fastq"))
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    junk_c = np.arange(37, dtype=np.uint16)
+    junk_p = np.arange(911, dtype=np.uint16)
+    rc, out = ctx.decode_block(e["seq"], e["qual"], np.concatenate([junk_c, e["n_count"]]),
+                               np.concatenate([junk_p, e["n_pos"]]), recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
+# ---------------------------------------------------------------- BASELINE size: properties only
+def test_full_size_roundtrip_1gib(F):
+    """configs[2] layout: 1 GiB of config-2 reads in 16 blocks of 64 MiB, tables from the first
+    128 MiB.  Size-independent properties: encode -> wipe -> batch decode restores every byte; the
+    streams of two blocks are additionally compared with the oracle bit for bit."""
+    n_blocks, bsz = 16, 64 << 20
+    blocks, raws, recss = [], [], []
+    next_id = 0
+    for i in range(n_blocks):
+        raw, n = F.synth_fastq(bsz, 2, seed=28, first_read_id=next_id)
+        next_id += n
+        raws.append(raw)
+        recss.append(F.parse_fastq(raw))
+    sample = np.concatenate(raws[:2])
+    srecs = F.parse_fastq(sample)
+    sft, qft = F.freq_tables(sample, srecs)
+    ctx = F.Context(sft, qft)
+    total = 0
+    for raw, recs in zip(raws, recss):
+        b = ctx.dblock(raw, recs)
+        b.encode()
+        blocks.append(b)
+        total += raw.size
+    ctx.sync()
+    sizes = []
+    for b in blocks:
+        rc, st = b.status()
+        assert rc == 0
+        assert b.refixed() == (0, 0) or sum(b.refixed()) < 100
+        sizes.append((st["seq_len"], st["qual_len"]))
+    # uniform ACGT cannot beat 2 bits/base; the model mismatch costs well under 0.1 %
+    bases = sum(int(r["len"].sum()) for r in recss)
+    assert bases / 4 <= sum(s for s, _ in sizes) <= bases / 4 * 1.001 + 16 * 2048
+    octx = O.OracleCtx(sft, qft)
+    for i in (0, 11):
+        e = octx.encode(raws[i], recss[i])
+        g = blocks[i].fetch()
+        assert np.array_equal(g["seq"], e["seq"]) and np.array_equal(g["qual"], e["qual"])
+    for b in blocks:
+        b.wipe()
+    ctx.sync()
+    assert not np.array_equal(blocks[3].fetch_raw(), raws[3])
+    ctx.decode_dblocks(blocks)
+    ctx.sync()
+    for b, raw in zip(blocks, raws):
+        rc, _ = b.status()
+        assert rc == 0
+        assert np.array_equal(b.fetch_raw(), raw)
+        b.close()
+    ctx.close()
+    assert total > (1 << 30) - 16 * 400
