@@ -32,7 +32,7 @@ class FqgpuError(RuntimeError):
 
 
 class Timing(C.Structure):
-    _fields_ = [("total_ms", C.c_float), ("kernel_ms", C.c_float * 24),
+    _fields_ = [("total_ms", C.c_float), ("kernel_ms", C.c_float * 24), ("kernel_calls", C.c_int * 24),
                 ("kernel_name", C.c_char_p * 24), ("n_kernels", C.c_int)]
 
 
@@ -81,7 +81,8 @@ _PROTOS = {
     "fqgpu_sync": (C.c_int, [C.c_void_p]),
     "fqgpu_dblock_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
-    "fqgpu_dblock_refixed": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "fqgpu_dblock_longest_chain": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "fqgpu_ctx_set_lanes": (C.c_int, [C.c_void_p, C.c_uint]),
     "fqgpu_dblock_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "fqgpu_dblock_load_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -201,9 +202,10 @@ class DBlock:
         rc = lib().fqgpu_dblock_status(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         return rc, dict(seq_len=a.value, qual_len=b.value, n_pos_len=c.value, n_bases=d.value)
 
-    def refixed(self):
+    def longest_chain(self):
+        """(seq, qual): longest serial run of symbols one lane walked in the last encode."""
         a, b = C.c_uint(), C.c_uint()
-        _check(lib().fqgpu_dblock_refixed(self.h, C.byref(a), C.byref(b)), "dblock_refixed")
+        _check(lib().fqgpu_dblock_longest_chain(self.h, C.byref(a), C.byref(b)), "dblock_longest_chain")
         return a.value, b.value
 
     def fetch(self, raw=False):
@@ -253,8 +255,11 @@ class Context:
 
     __del__ = close
 
-    def set_chain_params(self, segment=0, warmup=0):
-        _check(lib().fqgpu_ctx_set_chain_params(self.h, segment, warmup), "set_chain_params")
+    def set_chain_params(self, segment=0, seq_generic=False):
+        _check(lib().fqgpu_ctx_set_chain_params(self.h, segment, 1 if seq_generic else 0), "set_chain_params")
+
+    def set_lanes(self, lanes):
+        _check(lib().fqgpu_ctx_set_lanes(self.h, lanes), "set_lanes")
 
     def sync(self):
         _check(lib().fqgpu_sync(self.h), "sync")
@@ -265,7 +270,8 @@ class Context:
     def last_timing(self):
         t = Timing()
         _check(lib().fqgpu_ctx_last_timing(self.h, C.byref(t)), "last_timing")
-        return t.total_ms, [(t.kernel_name[i].decode(), t.kernel_ms[i]) for i in range(t.n_kernels)]
+        return t.total_ms, [(t.kernel_name[i].decode(), t.kernel_ms[i], t.kernel_calls[i])
+                            for i in range(t.n_kernels)]
 
     def dump_tables(self, stream, model):
         alpha = QUAL_ALPHA if stream else SEQ_ALPHA

@@ -60,43 +60,57 @@ static int use_device(int device) {
 }
 
 // ------------------------------------------------------------------ kernel timing
+// Spans = pairs of HIP events recorded on the stream the kernels run on.  Spans accumulate
+// from fqgpu_ctx_enable_timing(ctx, 1) until they are read; fqgpu_ctx_last_timing sums them
+// per label (total device time and number of launches of every kernel group).
 struct KernelTimer {
   bool on = false;
   std::vector<hipEvent_t> pool;
-  std::vector<const char *> names;  // names[i] labels the span ending at event i+1
   size_t used = 0;
-  hipEvent_t get() {
+  struct Span { const char *name; size_t b, e; };
+  std::vector<Span> spans;
+  hipEvent_t get(size_t *idx) {
     if (used == pool.size()) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return nullptr;
       pool.push_back(e);
     }
+    *idx = used;
     return pool[used++];
   }
 };
 
-void fq_timer_begin(fqgpu_ctx *ctx) {
+void fq_timer_span_begin(fqgpu_ctx *ctx, const char *name, hipStream_t st) {
   KernelTimer *t = ctx->timer;
   if (!t || !t->on) return;
-  t->used = 0;
-  t->names.clear();
-  hipEvent_t e = t->get();
-  if (e) (void)hipEventRecord(e, ctx->stream);
+  size_t i;
+  hipEvent_t e = t->get(&i);
+  if (!e) return;
+  (void)hipEventRecord(e, st);
+  t->spans.push_back({name, i, (size_t)-1});
 }
-void fq_timer_mark(fqgpu_ctx *ctx, const char *name) {
+void fq_timer_span_end(fqgpu_ctx *ctx, hipStream_t st) {
   KernelTimer *t = ctx->timer;
-  if (!t || !t->on || t->used == 0) return;
-  hipEvent_t e = t->get();
-  if (e) { (void)hipEventRecord(e, ctx->stream); t->names.push_back(name); }
+  if (!t || !t->on || t->spans.empty()) return;
+  // the matching begin is the last open span (launch code nests nothing across streams)
+  for (size_t k = t->spans.size(); k-- > 0;) {
+    if (t->spans[k].e == (size_t)-1) {
+      size_t i;
+      hipEvent_t e = t->get(&i);
+      if (!e) return;
+      (void)hipEventRecord(e, st);
+      t->spans[k].e = i;
+      return;
+    }
+  }
 }
-void fq_timer_end(fqgpu_ctx *) {}
 
 extern "C" int fqgpu_ctx_enable_timing(fqgpu_ctx *ctx, int on) {
   if (!ctx) return FQGPU_E_ARG;
   if (!ctx->timer) ctx->timer = new (std::nothrow) KernelTimer();
   if (!ctx->timer) return FQGPU_E_NOMEM;
   ctx->timer->on = on != 0;
-  ctx->timer->used = 0;
+  if (on) { ctx->timer->used = 0; ctx->timer->spans.clear(); }
   return FQGPU_OK;
 }
 
@@ -104,22 +118,57 @@ extern "C" int fqgpu_ctx_last_timing(fqgpu_ctx *ctx, fqgpu_timing *out) {
   if (!ctx || !out || !ctx->timer) return FQGPU_E_ARG;
   KernelTimer *t = ctx->timer;
   memset(out, 0, sizeof(*out));
-  if (t->used < 2) return FQGPU_OK;
-  int rc = use_device(ctx->device);
+  int rc = fqgpu_sync(ctx);
   if (rc) return rc;
-  FQ_HIP(hipEventSynchronize(t->pool[t->used - 1]));
-  FQ_HIP(hipEventElapsedTime(&out->total_ms, t->pool[0], t->pool[t->used - 1]));
-  // spans with the same label (there are none today) would be merged here
-  int n = 0;
-  for (size_t i = 0; i + 1 < t->used && n < 24; i++) {
-    float ms = 0;
-    FQ_HIP(hipEventElapsedTime(&ms, t->pool[i], t->pool[i + 1]));
-    out->kernel_ms[n] = ms;
-    out->kernel_name[n] = t->names[i];
-    n++;
+  float first_to_last = 0;
+  for (const KernelTimer::Span &sp : t->spans) {
+    if (sp.e == (size_t)-1) continue;
+    float ms = 0, span_end = 0;
+    FQ_HIP(hipEventElapsedTime(&ms, t->pool[sp.b], t->pool[sp.e]));
+    FQ_HIP(hipEventElapsedTime(&span_end, t->pool[t->spans[0].b], t->pool[sp.e]));
+    if (span_end > first_to_last) first_to_last = span_end;
+    int k = 0;
+    for (; k < out->n_kernels; k++) if (strcmp(out->kernel_name[k], sp.name) == 0) break;
+    if (k == out->n_kernels) {
+      if (k == 24) continue;
+      out->kernel_name[k] = sp.name;
+      out->n_kernels++;
+    }
+    out->kernel_ms[k] += ms;
+    out->kernel_calls[k] += 1;
   }
-  out->n_kernels = n;
+  out->total_ms = first_to_last;
   return FQGPU_OK;
+}
+
+// ------------------------------------------------------------------ encode lanes
+EncLane *fq_next_lane(fqgpu_ctx *ctx) {
+  EncLane &l = ctx->lanes[ctx->next_lane % ctx->n_lanes];
+  ctx->next_lane++;
+  if (!l.st_seq) {
+    if (hipStreamCreateWithFlags(&l.st_seq, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&l.st_qual, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming) != hipSuccess)
+      return nullptr;
+  }
+  return &l;
+}
+
+static void free_lane(EncLane &l) {
+  DevBuf *bufs[] = {&l.rec_start, &l.n_cnt32, &l.n_off, &l.scan_tmp};
+  for (DevBuf *b : bufs) b->release();
+  for (int s = 0; s < 2; s++) {
+    EncScratch &e = l.enc[s];
+    DevBuf *eb[] = {&e.slot_of, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
+                    &e.ctx_arrays, &e.seg_state, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
+    for (DevBuf *b : eb) b->release();
+  }
+  if (l.ev_fork) (void)hipEventDestroy(l.ev_fork);
+  if (l.ev_join) (void)hipEventDestroy(l.ev_join);
+  if (l.st_seq) (void)hipStreamDestroy(l.st_seq);
+  if (l.st_qual) (void)hipStreamDestroy(l.st_qual);
+  l = EncLane();
 }
 
 // ------------------------------------------------------------------ record validation (host)
@@ -288,17 +337,12 @@ extern "C" int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual
 extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)fqgpu_sync(ctx);
   free_tables(ctx->tab[0]);
   free_tables(ctx->tab[1]);
-  DevBuf *bufs[] = {&ctx->rec_start, &ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc, &ctx->tmp_result};
+  DevBuf *bufs[] = {&ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc};
   for (DevBuf *b : bufs) b->release();
-  for (int s = 0; s < 2; s++) {
-    EncScratch &e = ctx->enc[s];
-    DevBuf *eb[] = {&e.slot_of, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
-                    &e.ctx_arrays, &e.seg_state, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
-    for (DevBuf *b : eb) b->release();
-  }
+  for (int i = 0; i < FQ_MAX_LANES; i++) free_lane(ctx->lanes[i]);
   if (ctx->timer) {
     for (hipEvent_t e : ctx->timer->pool) (void)hipEventDestroy(e);
     delete ctx->timer;
@@ -307,13 +351,22 @@ extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
   delete ctx;
 }
 
-extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned warmup) {
+extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned flags) {
   if (!ctx) return FQGPU_E_ARG;
   if (segment) {
-    if (segment < 4 || segment > (1u << 20)) return FQGPU_E_ARG;
+    if (segment < 2 || segment > (1u << 24)) return FQGPU_E_ARG;
     ctx->seg_len = segment;
   }
-  ctx->warmup = warmup == 0xFFFFFFFFu ? 0 : (warmup ? warmup : ctx->warmup);
+  ctx->seq_generic = (flags & FQGPU_CHAIN_SEQ_GENERIC) ? 1 : 0;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_ctx_set_lanes(fqgpu_ctx *ctx, unsigned lanes) {
+  if (!ctx || lanes < 1 || lanes > FQ_MAX_LANES) return FQGPU_E_ARG;
+  int rc = fqgpu_sync(ctx);
+  if (rc) return rc;
+  ctx->n_lanes = lanes;
+  ctx->next_lane = 0;
   return FQGPU_OK;
 }
 
@@ -412,7 +465,11 @@ extern "C" int fqgpu_sync(fqgpu_ctx *ctx) {
   if (!ctx) return FQGPU_E_ARG;
   int rc = use_device(ctx->device);
   if (rc) return rc;
-  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < FQ_MAX_LANES; i++) {
+    if (ctx->lanes[i].st_seq) FQ_HIP(hipStreamSynchronize(ctx->lanes[i].st_seq));
+    if (ctx->lanes[i].st_qual) FQ_HIP(hipStreamSynchronize(ctx->lanes[i].st_qual));
+  }
+  if (ctx->stream) FQ_HIP(hipStreamSynchronize(ctx->stream));
   return FQGPU_OK;
 }
 
@@ -446,7 +503,7 @@ extern "C" int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_
   return rc;
 }
 
-extern "C" int fqgpu_dblock_refixed(const fqgpu_dblock *b, unsigned *seq_segments, unsigned *qual_segments) {
+extern "C" int fqgpu_dblock_longest_chain(const fqgpu_dblock *b, unsigned *seq_segments, unsigned *qual_segments) {
   if (!b) return FQGPU_E_ARG;
   (void)hipSetDevice(b->device);
   BlockResult tmp;
@@ -460,9 +517,8 @@ extern "C" int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t
                                   uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
                                   uint8_t *raw_out) {
   if (!ctx || !b) return FQGPU_E_ARG;
-  int rc = use_device(ctx->device);
+  int rc = fqgpu_sync(ctx);
   if (rc) return rc;
-  FQ_HIP(hipStreamSynchronize(ctx->stream));
   if (seq_out && b->seq_len) FQ_HIP(hipMemcpy(seq_out, b->seq, b->seq_len, hipMemcpyDeviceToHost));
   if (qual_out && b->qual_len) FQ_HIP(hipMemcpy(qual_out, b->qual, b->qual_len, hipMemcpyDeviceToHost));
   if (readlens_out) FQ_HIP(hipMemcpy(readlens_out, b->readlens, b->n_recs * 2, hipMemcpyDeviceToHost));
@@ -476,9 +532,8 @@ extern "C" int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const 
                                          const uint8_t *qual, size_t qual_len, const uint16_t *n_count,
                                          const uint16_t *n_pos, size_t n_pos_len) {
   if (!ctx || !b || !seq || !qual || !n_count || (!n_pos && n_pos_len)) return FQGPU_E_ARG;
-  int rc = use_device(ctx->device);
+  int rc = fqgpu_sync(ctx);
   if (rc) return rc;
-  FQ_HIP(hipStreamSynchronize(ctx->stream));
   // foreign streams may be larger than what this block's own encode would need
   if (seq_len + 64 > b->seq_cap + 64) {
     (void)hipFree(b->seq);

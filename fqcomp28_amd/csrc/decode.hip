@@ -186,6 +186,8 @@ k_wipe(uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R
 
 int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b) {
   const unsigned R = (unsigned)b->n_recs;
+  int rcs = fqgpu_sync(ctx);  // the block may still be in an encode lane
+  if (rcs) return rcs;
   if (!R) return FQGPU_OK;
   const unsigned blocks = (unsigned)min((size_t)(R + 3) / 4, (size_t)8192);
   hipLaunchKernelGGL(k_wipe, dim3(blocks), dim3(256), 0, ctx->stream, b->raw, b->recs, R);
@@ -196,6 +198,8 @@ int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b) {
 int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks) {
   hipStream_t st = ctx->stream;
   if (!n_blocks) return FQGPU_OK;
+  int rcs = fqgpu_sync(ctx);  // blocks may still be in an encode lane
+  if (rcs) return rcs;
   // job descriptors: pinned host staging is not worth it for a few KB; plain async copy
   // from a host vector that outlives the copy (we synchronise the copy right away)
   DecJob *host = new DecJob[n_blocks];
@@ -224,13 +228,14 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_block
   if (he != hipSuccess) return fq_hip_error(he, __FILE__, __LINE__);
   const DecJob *jobs = ctx->dec_desc.as<DecJob>();
 
-  fq_timer_begin(ctx);
   for (size_t i = 0; i < n_blocks; i++)
     FQ_HIP(hipMemsetAsync(blocks[i]->result, 0, sizeof(BlockResult), st));
   TabView ts = {ctx->tab[0].logs, ctx->tab[0].log_prefix, ctx->tab[0].dt, ctx->tab[0].dt_off};
   TabView tq = {ctx->tab[1].logs, ctx->tab[1].log_prefix, ctx->tab[1].dt, ctx->tab[1].dt_off};
+  fq_timer_span_begin(ctx, "decode", st);
   hipLaunchKernelGGL(k_decode, dim3((unsigned)(2 * n_blocks)), dim3(64), 0, st, jobs, (unsigned)n_blocks, ts, tq);
-  fq_timer_mark(ctx, "decode");
+  fq_timer_span_end(ctx, st);
+  fq_timer_span_begin(ctx, "npatch", st);
   const unsigned gx = (unsigned)min((r_max + 255) / 256, (size_t)4096);
   hipLaunchKernelGGL(k_gather_ncount, dim3(gx ? gx : 1, (unsigned)n_blocks), dim3(256), 0, st, jobs,
                      ctx->n_cnt32.as<uint32_t>());
@@ -239,8 +244,7 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_block
     return rc;
   hipLaunchKernelGGL(k_npatch, dim3(gx ? gx : 1, (unsigned)n_blocks), dim3(256), 0, st, jobs,
                      ctx->n_off.as<uint32_t>());
-  fq_timer_mark(ctx, "npatch");
-  fq_timer_end(ctx);
+  fq_timer_span_end(ctx, st);
   FQ_HIP(hipGetLastError());
   return FQGPU_OK;
 }

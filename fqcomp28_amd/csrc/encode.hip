@@ -12,12 +12,17 @@
 // symbols of that context.  Hence the decomposition:
 //   K1 tile_hist / K2 layout : counting sort keys = context, per-tile histograms + scan
 //   K3 scatter               : stable partition of the symbols by context
-//   K4 chains                : every context's chain cut into segments, one lane per
-//                              segment, the context's CTable in LDS; a segment starts
-//                              from a warm-up over the preceding symbols (tANS encoder
-//                              states forget their history) and records start/end state
-//   K5 fixup                 : start(k) == end(k-1) proves a segment exact; the rare
-//                              mismatches are re-run serially from the proven state
+//   K4 chains                : a tANS encoder state does NOT forget its history (measured:
+//                              with near power-of-two counts the transition is a near-
+//                              permutation of the reachable states), so a chain can only be
+//                              cut where the state is known without its past: right after a
+//                              symbol whose normalised count is 1 or -1 (ONE table cell, the
+//                              next state is the same from every state).  Quality chains are
+//                              cut at those "reset" symbols, one lane per piece, CTable in
+//                              LDS.  Sequence contexts have no such symbols (4 symbols of
+//                              ~1/4 each): one lane walks each (block, context) chain with a
+//                              [symbol][state] -> state table in LDS, and the parallelism is
+//                              contexts x blocks in flight.
 //   K6 bitcount/scan/pack    : per-symbol (nb,bits) gathered back into encode order,
 //                              exclusive scan of nb = bit offsets, bit packing through LDS
 //   K7 epilogue              : state flush + end mark + size/overflow
@@ -255,7 +260,7 @@ k_scatter(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   }
 }
 
-// ------------------------------------------------------------------ K4: speculative state chains
+// ------------------------------------------------------------------ K4: state chains
 struct LdsCTable {
   const uint16_t *state_table;
   const uint32_t *tt;  // {deltaFindState, deltaNbBits} pairs
@@ -286,20 +291,33 @@ __device__ __forceinline__ unsigned chain_step(const LdsCTable &t, unsigned &x, 
   return out;
 }
 
+// A symbol with normalised count 1 or -1 owns ONE table cell: deltaNbBits = (log<<16) - size,
+// every state emits `log` bits and lands on stateTable[1 + deltaFindState].
+__device__ __forceinline__ bool is_reset_symbol(const LdsCTable &t, unsigned sym) {
+  return t.tt[2 * sym + 1] == (t.log << 16) - (1u << t.log);
+}
+__device__ __forceinline__ unsigned reset_state(const LdsCTable &t, unsigned sym) {
+  return t.state_table[1 + (int)t.tt[2 * sym]];
+}
+
+// Generic chain kernel: the chain of a context is cut into nominal segments of S symbols,
+// 64 of them per wave.  The lane of segment k starts at the first position of its segment
+// whose predecessor is a reset symbol (or at 0 for k == 0) and keeps going -- across
+// segment borders -- until the next lane's start point.  Lanes without a start point idle:
+// their symbols are covered by the lane before.  Exact by construction, no verification.
 template <class M>
 __global__ void __launch_bounds__(64)
-k_chains(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-         const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
-         const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ spec_start,
-         uint16_t *__restrict__ seg_end, unsigned S, unsigned W) {
+k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
+               const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
+               const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state, unsigned S,
+               StreamResult *res) {
   extern __shared__ uint32_t lds[];
   constexpr unsigned B = M::B;
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
                  *item_base = seg_base + B + 1;
   const unsigned item = blockIdx.x;
   if (item >= item_base[B]) return;  // the grid is an upper bound
-  // context owning this work item: last c with item_base[c] <= item
-  unsigned lo = 0, hi = B - 1;
+  unsigned lo = 0, hi = B - 1;       // context owning this work item: last c with item_base[c] <= item
   while (lo < hi) {
     const unsigned mid = lo + ((hi - lo + 1) >> 1);
     if (item_base[mid] <= item) lo = mid; else hi = mid - 1;
@@ -310,74 +328,92 @@ k_chains(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
   const unsigned k = (item - item_base[c]) * 64 + fq_lane();
   const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
   if (k >= nseg) return;
-  const unsigned base = ctx_start[c];
-  const unsigned begin = k * S;
-  const unsigned end = min(n, begin + S);
-  unsigned x = 1u << t.log;  // FSE_initCState
-  if (k > 0) {               // warm-up: outputs discarded
-    const unsigned wb = begin > W ? begin - W : 0;
-    for (unsigned i = wb; i < begin; i++) (void)chain_step(t, x, sorted_sym[base + i]);
+  const uint8_t *sym = sorted_sym + ctx_start[c];
+  uint16_t *out = out16 + ctx_start[c];
+  const unsigned begin = k * S, end = min(n, begin + S);
+  // start point of this segment
+  unsigned i = begin, x = 1u << t.log;  // FSE_initCState for k == 0
+  if (k > 0) {
+    bool found = false;
+    for (unsigned j = begin; j < end; j++) {
+      const unsigned prev = sym[j - 1];
+      if (is_reset_symbol(t, prev)) { i = j; x = reset_state(t, prev); found = true; break; }
+    }
+    if (!found) return;
   }
-  const unsigned spec = x;
-  for (unsigned i = begin; i < end; i++) out16[base + i] = (uint16_t)chain_step(t, x, sorted_sym[base + i]);
-  spec_start[seg_base[c] + k] = (uint16_t)spec;
-  seg_end[seg_base[c] + k] = (uint16_t)x;
+  unsigned steps = 0;
+  for (;;) {
+    const unsigned sy = sym[i];
+    out[i] = (uint16_t)chain_step(t, x, sy);
+    i++; steps++;
+    if (i >= n) { final_state[c] = (uint16_t)x; break; }
+    if (i >= end && is_reset_symbol(t, sy)) break;  // the lane of a later segment starts here
+  }
+  atomicMax(&res->refixed, steps);  // longest serial run (diagnostic)
 }
 
-// ------------------------------------------------------------------ K5: verification + serial fix-up
-// Segment 0 starts from the true initial state.  If spec_start[k] == seg_end[k-1]
-// for every k, induction proves all segments exact.  A mismatching segment is re-run
-// from seg_end[k-1] (exact by induction), which may change seg_end[k] and thereby the
-// verdict on k+1.  One wave per context; lane 0 does the re-runs from an LDS table copy.
-template <class M>
+// Sequence chains: one wave per context, lane 0 walks the whole chain.  The transition
+// table is expanded to next[s][x - size] in LDS (4 << log entries, u16) so a step is one
+// add and one 2-byte LDS read on the critical path; symbols arrive 16 per 16-byte load.
 __global__ void __launch_bounds__(64)
-k_fixup(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-        const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
-        const uint32_t *__restrict__ ct_off, const uint16_t *__restrict__ spec_start,
-        uint16_t *__restrict__ seg_end, unsigned S, StreamResult *res) {
+k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
+            const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
+            const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state,
+            StreamResult *res) {
   extern __shared__ uint32_t lds[];
-  constexpr unsigned B = M::B;
-  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
+  constexpr unsigned B = SeqModel::B;
+  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
   const unsigned c = blockIdx.x;
   const unsigned n = ctx_count[c];
-  const unsigned nseg = (n + S - 1) / S;
-  if (nseg <= 1) return;
-  const unsigned sb = seg_base[c], base = ctx_start[c], lane = fq_lane();
-  bool staged = false;
-  LdsCTable t = {};
-  unsigned last_fixed = 0xFFFFFFFFu, last_end = 0, n_fixed = 0;
-  for (unsigned kb = 1; kb < nseg; kb += 64) {
-    const unsigned kk = kb + lane;
-    const bool valid = kk < nseg;
-    const unsigned s = valid ? spec_start[sb + kk] : 0u;
-    unsigned ep = valid ? seg_end[sb + kk - 1] : 0u;
-    if (valid && kk - 1 == last_fixed) ep = last_end;  // value still in flight to memory
-    unsigned long long mm = __ballot(valid && s != ep);
-    while (mm) {
-      const unsigned j = (unsigned)__ffsll((long long)mm) - 1u;
-      const unsigned k = kb + j;
-      mm &= mm - 1;
-      unsigned start = __shfl(ep, (int)j);
-      const unsigned sp = __shfl(s, (int)j);
-      if (k - 1 == last_fixed) start = last_end;
-      if (start == sp) continue;  // the previous re-run made this one consistent
-      if (!staged) { t = stage_ctable<M>(lds, ct + ct_off[c]); staged = true; }
-      unsigned x = start;
-      if (lane == 0) {
-        const unsigned begin = k * S, end = min(n, begin + S);
-        for (unsigned i = begin; i < end; i++)
-          out16[base + i] = (uint16_t)chain_step(t, x, sorted_sym[base + i]);
-        seg_end[sb + k] = (uint16_t)x;
-      }
-      x = __shfl(x, 0);
-      last_fixed = k; last_end = x; n_fixed++;
-      if (j + 1 < 64 && k + 1 < nseg) {  // re-judge the next segment against the new end state
-        const unsigned sp1 = __shfl(s, (int)(j + 1));
-        if (sp1 != x) mm |= 1ull << (j + 1); else mm &= ~(1ull << (j + 1));
-      }
-    }
+  if (n == 0) return;
+  const uint32_t *tbl = ct + ct_off[c];
+  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
+  const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
+  const uint32_t *tt = tbl + 1 + (size >> 1);
+  uint16_t *next = reinterpret_cast<uint16_t *>(lds);  // [4][size], values pre-scaled to byte offsets
+  unsigned dnb[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) dnb[s] = tt[2 * s + 1];
+  for (unsigned e = fq_lane(); e < 4 * size; e += 64) {
+    const unsigned s = e >> log, xi = e & (size - 1), x = size + xi;
+    const unsigned nb = (x + tt[2 * s + 1]) >> 16;
+    next[e] = (uint16_t)(((unsigned)st[(int)(x >> nb) + (int)tt[2 * s]] - size) * 2u);
   }
-  if (lane == 0 && n_fixed) atomicAdd(&res->refixed, n_fixed);
+  __syncthreads();
+  if (fq_lane() != 0) return;
+  const uint8_t *sym = sorted_sym + ctx_start[c];  // 16-byte aligned (CTX_PAD)
+  uint16_t *out = out16 + ctx_start[c];
+  const char *nbase = reinterpret_cast<const char *>(next);
+  unsigned xo = 0;  // (state - size) * 2
+  const unsigned n16 = n & ~15u;
+  uint4 cur = n16 ? *reinterpret_cast<const uint4 *>(sym) : make_uint4(0, 0, 0, 0);
+  for (unsigned i = 0; i < n16; i += 16) {
+    const uint4 nxt = (i + 16 < n16) ? *reinterpret_cast<const uint4 *>(sym + i + 16) : make_uint4(0, 0, 0, 0);
+    const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+    unsigned o[8];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & 3u;
+      const unsigned x = size + (xo >> 1);
+      const unsigned d = s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3];
+      const unsigned nb = (x + d) >> 16;
+      const unsigned v = (nb << 12) | (x & ((1u << nb) - 1u));
+      if (j & 1) o[j >> 1] |= v << 16; else o[j >> 1] = v;
+      xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+    }
+    *reinterpret_cast<uint4 *>(out + i) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4 *>(out + i + 8) = make_uint4(o[4], o[5], o[6], o[7]);
+    cur = nxt;
+  }
+  for (unsigned i = n16; i < n; i++) {
+    const unsigned s = sym[i] & 3u;
+    const unsigned x = size + (xo >> 1);
+    const unsigned nb = (x + (s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3])) >> 16;
+    out[i] = (uint16_t)((nb << 12) | (x & ((1u << nb) - 1u)));
+    xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+  }
+  final_state[c] = (uint16_t)(size + (xo >> 1));
+  atomicMax(&res->refixed, n);
 }
 
 // ------------------------------------------------------------------ K6: bit offsets and packing
@@ -482,17 +518,17 @@ k_pack(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16,
 
 // ------------------------------------------------------------------ K7: state flush + end mark
 // FSE_Encoder::endChunk (src/fse_common.hpp:86-90): states of context 0..B-1, log bits each,
-// then one '1' bit.  A context's final state is the end state of its last segment.
+// then one '1' bit.  A context never used in the block still holds its initial state 2^log.
 template <class M>
 __global__ void __launch_bounds__(256)
-k_epilogue(const uint32_t *__restrict__ arrays, const uint16_t *__restrict__ seg_end,
-           const uint32_t *__restrict__ logs, const uint32_t *__restrict__ log_prefix, unsigned S,
+k_epilogue(const uint32_t *__restrict__ arrays, const uint16_t *__restrict__ final_state,
+           const uint32_t *__restrict__ logs, const uint32_t *__restrict__ log_prefix,
            uint32_t *__restrict__ out, const StreamResult *res) {
   constexpr unsigned B = M::B;
   constexpr unsigned NW = (B * 12 + 1 + 31) / 32 + 2;
   __shared__ uint32_t words[NW];
   if (res->overflow) return;
-  const uint32_t *ctx_count = arrays, *seg_base = arrays + B + B + 1;
+  const uint32_t *ctx_count = arrays;
   for (unsigned i = threadIdx.x; i < NW; i += blockDim.x) words[i] = 0;
   __syncthreads();
   const unsigned long long p0 = res->total_bits;
@@ -502,7 +538,7 @@ k_epilogue(const uint32_t *__restrict__ arrays, const uint16_t *__restrict__ seg
     if (c < B) {
       const unsigned n = ctx_count[c];
       nb = logs[c];
-      val = n ? ((unsigned)seg_end[seg_base[c] + (n + S - 1) / S - 1] & ((1u << nb) - 1u)) : 0u;
+      val = n ? ((unsigned)final_state[c] & ((1u << nb) - 1u)) : 0u;
     } else { val = 1u; nb = 1u; }  // end mark
     const unsigned off = sh + log_prefix[c];  // log_prefix[B] = sum of logs
     const unsigned long long field = (unsigned long long)val << (off & 31u);
@@ -519,24 +555,26 @@ k_epilogue(const uint32_t *__restrict__ arrays, const uint16_t *__restrict__ seg
 }
 
 // ------------------------------------------------------------------ host orchestration
+#define FQ_SPAN_BEGIN(name) fq_timer_span_begin(ctx, name, st)
+#define FQ_SPAN_END() fq_timer_span_end(ctx, st)
+
 template <class M>
-int encode_stream(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint32_t *rec_start, uint8_t *out_dev,
-                  size_t cap) {
-  hipStream_t st = ctx->stream;
-  EncScratch &sc = ctx->enc[M::STREAM];
+int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b,
+                  const uint32_t *rec_start, uint8_t *out_dev, size_t cap) {
+  EncScratch &sc = lane.enc[M::STREAM];
   const DevTables &tab = ctx->tab[M::STREAM];
   constexpr unsigned B = M::B;
   const unsigned n_sym = (unsigned)b->n_bases;
   const unsigned R = (unsigned)b->n_recs;
   const unsigned T = tile_size<M>();
-  const unsigned S = ctx->seg_len, W = ctx->warmup;
+  const unsigned S = ctx->seg_len;
   const unsigned n_tiles = (n_sym + T - 1) / T;
   const unsigned n_groups = (n_tiles + GROUP_TILES - 1) / GROUP_TILES;
   const unsigned n_ptiles = (n_sym + PACK_TILE - 1) / PACK_TILE;
   const size_t padded = (size_t)n_sym + (size_t)CTX_PAD * B + 64;
-  const size_t max_segs = (size_t)n_sym / S + B + 1;
   const unsigned max_items = (unsigned)((size_t)n_sym / ((size_t)S * 64) + B + 1);
   StreamResult *res = &b->result->s[M::STREAM];
+  const bool serial_seq = M::STREAM == 0 && !ctx->seq_generic;
 
   int rc;
   if ((rc = sc.slot_of.reserve((size_t)n_sym * 4))) return rc;
@@ -546,18 +584,21 @@ int encode_stream(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint32_t *rec_start, ui
   if ((rc = sc.tile_base.reserve((size_t)n_tiles * B * 4))) return rc;
   if ((rc = sc.group_sum.reserve((size_t)n_groups * B * 4))) return rc;
   if ((rc = sc.ctx_arrays.reserve((size_t)(4 * B + 3) * 4))) return rc;
-  if ((rc = sc.seg_state.reserve(max_segs * 2 * 2))) return rc;
+  if ((rc = sc.seg_state.reserve((size_t)B * 2))) return rc;
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
   if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
 
   uint32_t *arrays = sc.ctx_arrays.as<uint32_t>();
-  uint16_t *spec_start = sc.seg_state.as<uint16_t>();
-  uint16_t *seg_end = spec_start + max_segs;
+  uint16_t *final_state = sc.seg_state.as<uint16_t>();
   const unsigned lds_ct = (1u + (1u << (tab.max_log - 1)) + 2u * M::A) * 4u;
+  const char *pfx = M::STREAM ? "qual." : "seq.";
+  (void)pfx;
 
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");
   hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R,
                      n_sym, T, sc.tile_hist.as<uint32_t>(), res);
-  fq_timer_mark(ctx, M::STREAM ? "qual.tile_hist" : "seq.tile_hist");
+  FQ_SPAN_END();
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");
   hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
   hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, sc.group_sum.as<uint32_t>(), n_groups,
@@ -565,20 +606,26 @@ int encode_stream(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint32_t *rec_start, ui
   hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B,
                      sc.tile_base.as<uint32_t>());
-  fq_timer_mark(ctx, M::STREAM ? "qual.layout" : "seq.layout");
+  FQ_SPAN_END();
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");
   hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, b->raw, b->recs, rec_start, R,
                      n_sym, T, sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
                      sc.slot_of.as<uint32_t>());
-  fq_timer_mark(ctx, M::STREAM ? "qual.scatter" : "seq.scatter");
-  hipLaunchKernelGGL(k_chains<M>, dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
-                     sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, spec_start, seg_end, S, W);
-  fq_timer_mark(ctx, M::STREAM ? "qual.chains" : "seq.chains");
-  hipLaunchKernelGGL(k_fixup<M>, dim3(B), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
-                     sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, spec_start, seg_end, S, res);
-  fq_timer_mark(ctx, M::STREAM ? "qual.fixup" : "seq.fixup");
+  FQ_SPAN_END();
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
+  if (serial_seq) {
+    hipLaunchKernelGGL(k_chain_seq, dim3(B), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
+                       sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, res);
+  } else {
+    hipLaunchKernelGGL(k_chains_reset<M>, dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                       sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, res);
+  }
+  FQ_SPAN_END();
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.bitcount" : "seq.bitcount");
   hipLaunchKernelGGL(k_bitcount, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
                      sc.out16.as<uint16_t>(), n_sym, sc.tile_bits.as<uint32_t>());
-  fq_timer_mark(ctx, M::STREAM ? "qual.bitcount" : "seq.bitcount");
+  FQ_SPAN_END();
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.bitscan" : "seq.bitscan");
   if ((rc = fq_scan_u32_to_u64(st, sc.tile_bits.as<uint32_t>(), n_ptiles,
                                sc.tile_bit_base.as<unsigned long long>(), sc.scan_tmp)))
     return rc;
@@ -587,49 +634,63 @@ int encode_stream(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint32_t *rec_start, ui
   hipLaunchKernelGGL(k_zero_bounds, dim3((n_ptiles + 256) / 256), dim3(256), 0, st,
                      sc.tile_bit_base.as<unsigned long long>(), n_ptiles,
                      reinterpret_cast<uint32_t *>(out_dev), res);
-  fq_timer_mark(ctx, M::STREAM ? "qual.bitscan" : "seq.bitscan");
+  FQ_SPAN_END();
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.pack" : "seq.pack");
   hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
                      sc.out16.as<uint16_t>(), n_sym, sc.tile_bit_base.as<unsigned long long>(),
                      reinterpret_cast<uint32_t *>(out_dev), res);
-  fq_timer_mark(ctx, M::STREAM ? "qual.pack" : "seq.pack");
-  hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, seg_end, tab.logs,
-                     tab.log_prefix, S, reinterpret_cast<uint32_t *>(out_dev), res);
-  fq_timer_mark(ctx, M::STREAM ? "qual.epilogue" : "seq.epilogue");
+  FQ_SPAN_END();
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.epilogue" : "seq.epilogue");
+  hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, final_state, tab.logs,
+                     tab.log_prefix, reinterpret_cast<uint32_t *>(out_dev), res);
+  FQ_SPAN_END();
   FQ_HIP(hipGetLastError());
   return FQGPU_OK;
 }
 
 }  // namespace
 
+// One block = one encode lane: two HIP streams (sequence pipeline, quality pipeline) forked
+// after the record-level kernels and joined before the N-position pass.  Blocks handed to
+// different lanes overlap on the device: the serial sequence chains of one block hide behind
+// the bandwidth-bound passes of the others.
 int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
-  hipStream_t st = ctx->stream;
   const unsigned R = (unsigned)b->n_recs;
   if (R == 0 || b->n_bases == 0) return FQGPU_E_ARG;
+  EncLane *lp = fq_next_lane(ctx);
+  if (!lp) return FQGPU_E_NOMEM;
+  EncLane &lane = *lp;
+  hipStream_t st = lane.st_seq;
   int rc;
-  if ((rc = ctx->rec_start.reserve((size_t)(R + 1) * 4))) return rc;
-  if ((rc = ctx->n_cnt32.reserve((size_t)R * 4 * 2))) return rc;  // n_cnt32 | lens32
-  if ((rc = ctx->n_off.reserve((size_t)(R + 1) * 4))) return rc;
-  uint32_t *n_cnt32 = ctx->n_cnt32.as<uint32_t>();
+  if ((rc = lane.rec_start.reserve((size_t)(R + 1) * 4))) return rc;
+  if ((rc = lane.n_cnt32.reserve((size_t)R * 4 * 2))) return rc;  // n_cnt32 | lens32
+  if ((rc = lane.n_off.reserve((size_t)(R + 1) * 4))) return rc;
+  uint32_t *n_cnt32 = lane.n_cnt32.as<uint32_t>();
   uint32_t *lens32 = n_cnt32 + R;
+  uint32_t *rec_start = lane.rec_start.as<uint32_t>();
 
-  fq_timer_begin(ctx);
   FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), st));
   const unsigned rec_blocks = (unsigned)min((size_t)(R + 3) / 4, (size_t)8192);
+  FQ_SPAN_BEGIN("records");
   hipLaunchKernelGGL(k_readlens_ncount, dim3(rec_blocks), dim3(256), 0, st, b->raw, b->recs, R,
                      b->readlens, b->n_count, n_cnt32, lens32);
-  if ((rc = fq_scan_u32_to_u32(st, lens32, R, ctx->rec_start.as<uint32_t>(), ctx->scan_tmp))) return rc;
-  if ((rc = fq_scan_u32_to_u32(st, n_cnt32, R, ctx->n_off.as<uint32_t>(), ctx->scan_tmp))) return rc;
-  hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, ctx->n_off.as<uint32_t>(), R, b->result);
-  fq_timer_mark(ctx, "records");
+  if ((rc = fq_scan_u32_to_u32(st, lens32, R, rec_start, lane.scan_tmp))) return rc;
+  if ((rc = fq_scan_u32_to_u32(st, n_cnt32, R, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
+  hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
+  FQ_SPAN_END();
 
-  if ((rc = encode_stream<SeqModel>(ctx, b, ctx->rec_start.as<uint32_t>(), b->seq, b->seq_cap))) return rc;
-  if ((rc = encode_stream<QualModel>(ctx, b, ctx->rec_start.as<uint32_t>(), b->qual, b->qual_cap))) return rc;
+  FQ_HIP(hipEventRecord(lane.ev_fork, lane.st_seq));
+  FQ_HIP(hipStreamWaitEvent(lane.st_qual, lane.ev_fork, 0));
+  if ((rc = encode_stream<QualModel>(ctx, lane, lane.st_qual, b, rec_start, b->qual, b->qual_cap))) return rc;
+  if ((rc = encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, b->seq, b->seq_cap))) return rc;
+  FQ_HIP(hipEventRecord(lane.ev_join, lane.st_qual));
+  FQ_HIP(hipStreamWaitEvent(lane.st_seq, lane.ev_join, 0));
 
   // after both streams: the optional in-place N -> A must not race with their reads of raw
+  FQ_SPAN_BEGIN("npos");
   hipLaunchKernelGGL(k_npos, dim3(rec_blocks), dim3(256), 0, st, b->raw, b->recs, R,
-                     ctx->n_off.as<uint32_t>(), b->n_pos, (flags & FQGPU_F_WRITE_BACK_N) ? 1 : 0);
-  fq_timer_mark(ctx, "npos");
-  fq_timer_end(ctx);
+                     lane.n_off.as<uint32_t>(), b->n_pos, (flags & FQGPU_F_WRITE_BACK_N) ? 1 : 0);
+  FQ_SPAN_END();
   FQ_HIP(hipGetLastError());
   return FQGPU_OK;
 }

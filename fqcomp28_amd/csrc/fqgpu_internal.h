@@ -103,21 +103,35 @@ struct EncScratch {
   DevBuf scan_tmp;    // u64 chunk sums for the scans
 };
 
-struct fqgpu_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  DevTables tab[2];
-  unsigned seg_len = 512, warmup = 64;
-  // scratch shared by both streams of a block
+// One encode lane: everything a block needs while it is being coded, so that several
+// blocks can be in flight on one GPU (two HIP streams: sequence and quality pipelines).
+struct EncLane {
+  hipStream_t st_seq = nullptr, st_qual = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevBuf rec_start;   // u32 [R+1] first encode index of each record
-  DevBuf n_cnt32;     // u32 [R]
+  DevBuf n_cnt32;     // u32 [R] N count | u32 [R] length
   DevBuf n_off;       // u32 [R+1]
   DevBuf scan_tmp;
   EncScratch enc[2];
+};
+
+#define FQ_MAX_LANES 8
+
+struct fqgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;  // uploads, decode
+  DevTables tab[2];
+  unsigned seg_len = 1024;       // nominal segment of the reset-cut chain kernel
+  int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
+  unsigned n_lanes = 4, next_lane = 0;
+  EncLane lanes[FQ_MAX_LANES];
+  // decode scratch
+  DevBuf n_cnt32, n_off, scan_tmp;
   DevBuf dec_desc;    // decode job descriptors
-  DevBuf tmp_result;  // BlockResult for host-pointer calls
   KernelTimer *timer = nullptr;
 };
+
+EncLane *fq_next_lane(fqgpu_ctx *ctx);  // api.hip: round-robin, creates streams on first use
 
 struct fqgpu_dblock {
   int device = 0;
@@ -151,10 +165,9 @@ int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);
 int fq_scan_u32_to_u32(hipStream_t st, const uint32_t *in, size_t n, uint32_t *out, DevBuf &tmp);
 int fq_scan_u32_to_u64(hipStream_t st, const uint32_t *in, size_t n, unsigned long long *out, DevBuf &tmp);
 
-// kernel timing hooks (api.cpp)
-void fq_timer_begin(fqgpu_ctx *ctx);
-void fq_timer_mark(fqgpu_ctx *ctx, const char *name);  // call after each launch
-void fq_timer_end(fqgpu_ctx *ctx);
+// kernel timing hooks (api.hip): HIP events on the stream the kernels are launched on
+void fq_timer_span_begin(fqgpu_ctx *ctx, const char *name, hipStream_t st);
+void fq_timer_span_end(fqgpu_ctx *ctx, hipStream_t st);
 
 // ---------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)

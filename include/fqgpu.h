@@ -83,9 +83,16 @@ int fqgpu_tables_from_counts(int device, const uint32_t *seq_counts, const uint3
  * the device from the FreqTable PODs).  One per (host thread, GPU). */
 int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual_ft, fqgpu_ctx **out);
 void fqgpu_ctx_destroy(fqgpu_ctx *ctx);
-/* Tuning knobs of the speculative state-chain kernels (segment length and
- * warm-up, in symbols; 0 keeps the default).  Results never depend on them. */
-int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned warmup);
+/* Tuning knobs of the state-chain kernels; results never depend on them.
+ * segment: nominal length, in symbols, of the pieces a context's chain is cut into at
+ * single-state ("reset") symbols (0 keeps the default).  flags: FQGPU_CHAIN_SEQ_GENERIC
+ * runs the sequence stream through the same reset-cut kernel instead of the serial
+ * one-lane-per-context kernel. */
+#define FQGPU_CHAIN_SEQ_GENERIC 1u
+int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned flags);
+/* Number of blocks the handle keeps in flight (encode lanes, 1..8, default 4): each
+ * fqgpu_dblock_encode goes to the next lane (own HIP streams and scratch). */
+int fqgpu_ctx_set_lanes(fqgpu_ctx *ctx, unsigned lanes);
 /* Test hook: copies the device-built tables of one context out in zstd's memory
  * layout (FSE_CTable / FSE_DTable u32 words).  stream: 0 = sequence, 1 = quality. */
 int fqgpu_ctx_dump_tables(fqgpu_ctx *ctx, int stream, unsigned model, uint32_t *ctable_out,
@@ -140,9 +147,9 @@ int fqgpu_sync(fqgpu_ctx *ctx);
 /* status/sizes of the last encode/decode of this block (after fqgpu_sync) */
 int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_t *qual_len,
                         size_t *n_pos_len, size_t *n_bases);
-/* diagnostics of the last encode (after fqgpu_sync): how many chain segments per
- * stream the verification pass found mis-speculated and re-ran serially */
-int fqgpu_dblock_refixed(const fqgpu_dblock *b, unsigned *seq_segments, unsigned *qual_segments);
+/* diagnostics of the last encode (after fqgpu_sync): the longest run of symbols one lane
+ * had to walk serially, per stream (the latency floor of the chain kernels) */
+int fqgpu_dblock_longest_chain(const fqgpu_dblock *b, unsigned *seq_steps, unsigned *qual_steps);
 /* copies results to the host (synchronous); any pointer may be NULL */
 int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t *seq_out, uint8_t *qual_out,
                        uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
@@ -152,12 +159,13 @@ int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint8_t *se
                               const uint8_t *qual, size_t qual_len, const uint16_t *n_count,
                               const uint16_t *n_pos, size_t n_pos_len);
 
-/* Device time (ms) spent between the start and the end of the last
- * fqgpu_dblock_encode / fqgpu_dblocks_decode on this handle, measured with HIP
- * events on the handle's own stream; per-kernel times for the roofline line. */
+/* Device time per kernel group, measured with HIP events on the streams the kernels are
+ * launched on, accumulated from fqgpu_ctx_enable_timing(ctx, 1) until read: kernel_ms =
+ * summed duration, kernel_calls = number of launches; total_ms = first start to last end. */
 typedef struct {
   float total_ms;
   float kernel_ms[24];
+  int kernel_calls[24];
   const char *kernel_name[24];
   int n_kernels;
 } fqgpu_timing;

@@ -45,7 +45,7 @@ def run(name, raw, recs, seg=None, warm=None):
 
     ctx = F.Context(sft, qft)
     if seg is not None:
-        ctx.set_chain_params(seg, warm if warm else 0xFFFFFFFF)
+        ctx.set_chain_params(seg, bool(warm))
     L = O.lib()
     bad = 0
     for stream, ft, alpha, nm in ((0, sft, 4, 256), (1, qft, 64, 8192)):
@@ -90,4 +90,4 @@ if __name__ == "__main__":
             raw, recs = O.load_fastq(os.path.join(HERE, "golden", n + ".fastq"))
         run(n, raw, recs)
         if len(recs) > 100:
-            run(n + " seg=64 warm=0", raw, recs, seg=64, warm=None)
+            run(n + " seg=64 generic", raw, recs, seg=64, warm=True)
