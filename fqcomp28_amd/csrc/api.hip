@@ -8,6 +8,12 @@
 #include <new>
 #include <vector>
 
+// The encode lanes use up to 8 streams (two per block in flight).  ROCm maps streams onto
+// GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
+// run back to back; ask for 8 before the runtime initialises (no effect if the host
+// application already initialised HIP or set the variable itself).
+__attribute__((constructor)) static void fq_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 // ------------------------------------------------------------------ errors
 static thread_local char g_hip_msg[256] = "";
 

@@ -353,67 +353,78 @@ k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ ou
 }
 
 // Sequence chains: one wave per context, lane 0 walks the whole chain.  The transition
-// table is expanded to next[s][x - size] in LDS (4 << log entries, u16) so a step is one
-// add and one 2-byte LDS read on the critical path; symbols arrive 16 per 16-byte load.
+// table is expanded to next[s][x - size] in LDS (4 << log entries, u16, pre-scaled to byte
+// offsets) so a step is one add and one 2-byte LDS read on the critical path.  The chain
+// lane never touches global memory: the wave stages SEQ_CHUNK symbols into LDS with
+// coalesced 16-byte loads, lane 0 walks them LDS -> LDS, the wave stores the chunk's
+// outputs with coalesced 16-byte stores.
+constexpr unsigned SEQ_CHUNK = 4096;
+
 __global__ void __launch_bounds__(64)
 k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
             const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
             const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state,
             StreamResult *res) {
   extern __shared__ uint32_t lds[];
+  __shared__ uint4 symbuf[SEQ_CHUNK / 16];
+  __shared__ uint4 outbuf[SEQ_CHUNK / 8];
   constexpr unsigned B = SeqModel::B;
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
-  const unsigned c = blockIdx.x;
+  const unsigned c = blockIdx.x, lane = fq_lane();
   const unsigned n = ctx_count[c];
   if (n == 0) return;
   const uint32_t *tbl = ct + ct_off[c];
   const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
   const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
   const uint32_t *tt = tbl + 1 + (size >> 1);
-  uint16_t *next = reinterpret_cast<uint16_t *>(lds);  // [4][size], values pre-scaled to byte offsets
+  uint16_t *next = reinterpret_cast<uint16_t *>(lds);  // [4][size]
   unsigned dnb[4];
 #pragma unroll
   for (int s = 0; s < 4; s++) dnb[s] = tt[2 * s + 1];
-  for (unsigned e = fq_lane(); e < 4 * size; e += 64) {
+  for (unsigned e = lane; e < 4 * size; e += 64) {
     const unsigned s = e >> log, xi = e & (size - 1), x = size + xi;
     const unsigned nb = (x + tt[2 * s + 1]) >> 16;
     next[e] = (uint16_t)(((unsigned)st[(int)(x >> nb) + (int)tt[2 * s]] - size) * 2u);
   }
-  __syncthreads();
-  if (fq_lane() != 0) return;
-  const uint8_t *sym = sorted_sym + ctx_start[c];  // 16-byte aligned (CTX_PAD)
-  uint16_t *out = out16 + ctx_start[c];
+  const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + ctx_start[c]);  // 16-byte aligned (CTX_PAD)
+  uint4 *gout = reinterpret_cast<uint4 *>(out16 + ctx_start[c]);
   const char *nbase = reinterpret_cast<const char *>(next);
-  unsigned xo = 0;  // (state - size) * 2
-  const unsigned n16 = n & ~15u;
-  uint4 cur = n16 ? *reinterpret_cast<const uint4 *>(sym) : make_uint4(0, 0, 0, 0);
-  for (unsigned i = 0; i < n16; i += 16) {
-    const uint4 nxt = (i + 16 < n16) ? *reinterpret_cast<const uint4 *>(sym + i + 16) : make_uint4(0, 0, 0, 0);
-    const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
-    unsigned o[8];
+  unsigned xo = 0;  // (state - size) * 2, meaningful in lane 0 only
+  for (unsigned c0 = 0; c0 < n; c0 += SEQ_CHUNK) {
+    const unsigned len = min(SEQ_CHUNK, n - c0);
+    const unsigned q16 = (len + 15) >> 4;  // the run is padded to 16, reading the pad is harmless
+    for (unsigned v = lane; v < q16; v += 64) symbuf[v] = gsym[(c0 >> 4) + v];
+    __syncthreads();
+    if (lane == 0) {
+      for (unsigned g = 0; g < q16; g++) {
+        const uint4 sv = symbuf[g];
+        const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
+        unsigned o[8];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & 3u;
-      const unsigned x = size + (xo >> 1);
-      const unsigned d = s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3];
-      const unsigned nb = (x + d) >> 16;
-      const unsigned v = (nb << 12) | (x & ((1u << nb) - 1u));
-      if (j & 1) o[j >> 1] |= v << 16; else o[j >> 1] = v;
-      xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+        for (int j = 0; j < 16; j++) {
+          const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & 3u;
+          const unsigned x = size + (xo >> 1);
+          const unsigned d = s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3];
+          const unsigned nb = (x + d) >> 16;
+          const unsigned v = (nb << 12) | (x & ((1u << nb) - 1u));
+          if (j & 1) o[j >> 1] |= v << 16; else o[j >> 1] = v;
+          // symbols of the pad behind the run must not move the state
+          const unsigned nx = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+          xo = (g * 16 + j < len) ? nx : xo;
+        }
+        outbuf[2 * g] = make_uint4(o[0], o[1], o[2], o[3]);
+        outbuf[2 * g + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+      }
     }
-    *reinterpret_cast<uint4 *>(out + i) = make_uint4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<uint4 *>(out + i + 8) = make_uint4(o[4], o[5], o[6], o[7]);
-    cur = nxt;
+    __syncthreads();
+    const unsigned q8 = (len + 7) >> 3;
+    for (unsigned v = lane; v < q8; v += 64) gout[(c0 >> 3) + v] = outbuf[v];
+    __syncthreads();
   }
-  for (unsigned i = n16; i < n; i++) {
-    const unsigned s = sym[i] & 3u;
-    const unsigned x = size + (xo >> 1);
-    const unsigned nb = (x + (s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3])) >> 16;
-    out[i] = (uint16_t)((nb << 12) | (x & ((1u << nb) - 1u)));
-    xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+  if (lane == 0) {
+    final_state[c] = (uint16_t)(size + (xo >> 1));
+    atomicMax(&res->refixed, n);
   }
-  final_state[c] = (uint16_t)(size + (xo >> 1));
-  atomicMax(&res->refixed, n);
 }
 
 // ------------------------------------------------------------------ K6: bit offsets and packing

@@ -332,7 +332,8 @@ def test_full_size_roundtrip_1gib(F):
         ls, lq = b.longest_chain()
         # sequence chains are serial per context (~1/256 of the bases); quality chains are cut at
         # single-state symbols, so no lane walks more than a small part of the hottest context
-        assert ls < st["n_bases"] // 128 and lq < st["n_bases"] // 512
+        # (context 0xD7 also receives the first base of every read)
+        assert ls <= st["n_bases"] // 200 + len(recss[0]) + 4096 and lq < st["n_bases"] // 512
         sizes.append((st["seq_len"], st["qual_len"]))
     # uniform ACGT cannot beat 2 bits/base; the model mismatch costs well under 0.1 %
     bases = sum(int(r["len"].sum()) for r in recss)
