@@ -352,12 +352,13 @@ k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ ou
   atomicMax(&res->refixed, steps);  // longest serial run (diagnostic)
 }
 
-// Sequence chains: one wave per context, lane 0 walks the whole chain.  The transition
-// table is expanded to next[s][x - size] in LDS (4 << log entries, u16, pre-scaled to byte
-// offsets) so a step is one add and one 2-byte LDS read on the critical path.  The chain
-// lane never touches global memory: the wave stages SEQ_CHUNK symbols into LDS with
-// coalesced 16-byte loads, lane 0 walks them LDS -> LDS, the wave stores the chunk's
-// outputs with coalesced 16-byte stores.
+// Sequence chains: one wave per context.  A chain step on the critical path is one add and
+// one 2-byte LDS read (measured 62.5 shader cycles = 26 ns, tools/chain_ubench.hip): the
+// transition table is expanded to next[s][x - size] in LDS (4 << log u16 entries, pre-scaled
+// to byte offsets).  Per SEQ_CHUNK symbols: the wave stages the symbols into LDS with
+// coalesced 16-byte loads; lane 0 walks the chain LDS -> LDS and records only the state in
+// front of every symbol; then all 64 lanes turn (state, symbol) into the packed (nb, bits)
+// outputs in parallel and store them coalesced.  The chain lane never waits on global memory.
 constexpr unsigned SEQ_CHUNK = 4096;
 
 __global__ void __launch_bounds__(64)
@@ -367,7 +368,7 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
             StreamResult *res) {
   extern __shared__ uint32_t lds[];
   __shared__ uint4 symbuf[SEQ_CHUNK / 16];
-  __shared__ uint4 outbuf[SEQ_CHUNK / 8];
+  __shared__ uint16_t statebuf[SEQ_CHUNK];  // (state - size) * 2 in front of every symbol
   constexpr unsigned B = SeqModel::B;
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
   const unsigned c = blockIdx.x, lane = fq_lane();
@@ -389,6 +390,7 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
   const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + ctx_start[c]);  // 16-byte aligned (CTX_PAD)
   uint4 *gout = reinterpret_cast<uint4 *>(out16 + ctx_start[c]);
   const char *nbase = reinterpret_cast<const char *>(next);
+  const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf);
   unsigned xo = 0;  // (state - size) * 2, meaningful in lane 0 only
   for (unsigned c0 = 0; c0 < n; c0 += SEQ_CHUNK) {
     const unsigned len = min(SEQ_CHUNK, n - c0);
@@ -396,29 +398,39 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
     for (unsigned v = lane; v < q16; v += 64) symbuf[v] = gsym[(c0 >> 4) + v];
     __syncthreads();
     if (lane == 0) {
-      for (unsigned g = 0; g < q16; g++) {
+      const unsigned full = len >> 4;
+      for (unsigned g = 0; g < full; g++) {
         const uint4 sv = symbuf[g];
         const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
-        unsigned o[8];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
           const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & 3u;
-          const unsigned x = size + (xo >> 1);
-          const unsigned d = s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3];
-          const unsigned nb = (x + d) >> 16;
-          const unsigned v = (nb << 12) | (x & ((1u << nb) - 1u));
-          if (j & 1) o[j >> 1] |= v << 16; else o[j >> 1] = v;
-          // symbols of the pad behind the run must not move the state
-          const unsigned nx = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
-          xo = (g * 16 + j < len) ? nx : xo;
+          statebuf[g * 16 + j] = (uint16_t)xo;
+          xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
         }
-        outbuf[2 * g] = make_uint4(o[0], o[1], o[2], o[3]);
-        outbuf[2 * g + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+      }
+      for (unsigned i = full << 4; i < len; i++) {
+        const unsigned s = sbytes[i] & 3u;
+        statebuf[i] = (uint16_t)xo;
+        xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
       }
     }
     __syncthreads();
+    // (state, symbol) -> (nb << 12 | low nb bits of the state): FSE_encodeSymbol's emission
     const unsigned q8 = (len + 7) >> 3;
-    for (unsigned v = lane; v < q8; v += 64) gout[(c0 >> 3) + v] = outbuf[v];
+    for (unsigned v = lane; v < q8; v += 64) {
+      unsigned o[4];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const unsigned i = v * 8 + j;
+        const unsigned s = sbytes[i] & 3u;
+        const unsigned x = size + ((unsigned)statebuf[i] >> 1);
+        const unsigned nb = (x + (s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3])) >> 16;
+        const unsigned val = (nb << 12) | (x & ((1u << nb) - 1u));
+        if (j & 1) o[j >> 1] |= val << 16; else o[j >> 1] = val;
+      }
+      gout[(c0 >> 3) + v] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
     __syncthreads();
   }
   if (lane == 0) {
