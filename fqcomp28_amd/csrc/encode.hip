@@ -100,6 +100,36 @@ __global__ void k_store_npos_len(const uint32_t *__restrict__ n_off, unsigned R,
   res->n_pos_len = n_off[R];
 }
 
+// ------------------------------------------------------------------ walking symbols in encode order
+// Encode order = records in file order, positions L-1 .. 0 inside a record
+// (src/fse_sequence.cpp:76-77,101; src/fse_quality.cpp:7,19).  A wave walks a range of encode
+// indices 64 at a time; the record of every lane is found by stepping through the (few)
+// records a chunk touches with wave-uniform loads instead of a per-lane binary search.
+struct SymbolWalker {
+  const fqgpu_rec *__restrict__ recs;
+  const uint32_t *__restrict__ rec_start;
+  unsigned r;  // record holding the first symbol of the next chunk (wave-uniform)
+
+  // lanes with valid == true get their record and position; returns nothing else
+  __device__ __forceinline__ void locate(unsigned eb, unsigned e_end, unsigned e, bool valid,
+                                         fqgpu_rec &rec, unsigned &p) {
+    const unsigned chunk_end = min(eb + 64u, e_end);
+    unsigned rr = r;
+    rec.seq_off = rec.qual_off = rec.len = 0;
+    p = 0;
+    for (;;) {
+      rr = __builtin_amdgcn_readfirstlane(rr);
+      const unsigned rs = rec_start[rr], rn = rec_start[rr + 1];
+      const fqgpu_rec cand = recs[rr];
+      if (valid && e >= rs && e < rn) { rec = cand; p = cand.len - 1u - (e - rs); }
+      if (rn > chunk_end) break;            // record rr continues into the next chunk
+      rr++;
+      if (rn == chunk_end) break;           // next chunk starts exactly at record rr
+    }
+    r = rr;
+  }
+};
+
 // ------------------------------------------------------------------ K1: per-tile context histogram
 template <class M>
 __global__ void __launch_bounds__(256)
@@ -107,26 +137,31 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
             const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
             uint32_t *__restrict__ tile_hist, StreamResult *res) {
   __shared__ uint32_t hist[M::B];
-  __shared__ unsigned s_r0, s_r1;
   const unsigned tile = blockIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
   for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x) hist[c] = 0;
-  if (threadIdx.x == 0) {
-    s_r0 = fq_locate(rec_start, 0, R - 1, e0);
-    s_r1 = fq_locate(rec_start, 0, R - 1, e1 - 1);
-  }
   __syncthreads();
-  const unsigned r0 = s_r0, r1 = s_r1;
+  // every wave takes a contiguous quarter of the tile (multiple of 64 symbols)
+  const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
+  const unsigned per = (((e1 - e0) + 255u) / 256u) * 64u;
+  const unsigned wb = min(e0 + wave * per, e1), we = min(wb + per, e1);
   bool bad = false;
-  for (unsigned e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-    const unsigned r = fq_locate(rec_start, r0, r1, e);
-    const fqgpu_rec rec = recs[r];
-    const unsigned p = rec.len - 1u - (e - rec_start[r]);
-    unsigned ctx, sym;
-    fq_sym_ctx<M>(raw, rec, p, ctx, sym);
-    bad |= sym >= (unsigned)M::A;
-    atomicAdd(&hist[ctx], 1u);
+  if (wb < we) {
+    SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb)};
+    for (unsigned eb = wb; eb < we; eb += 64) {
+      const unsigned e = eb + lane;
+      const bool valid = e < we;
+      fqgpu_rec rec;
+      unsigned p;
+      w.locate(eb, we, e, valid, rec, p);
+      if (valid) {
+        unsigned ctx, sym;
+        fq_sym_ctx<M>(raw, rec, p, ctx, sym);
+        bad |= sym >= (unsigned)M::A;
+        atomicAdd(&hist[ctx], 1u);
+      }
+    }
   }
   if (bad) atomicOr(&res->bad_symbol, 1u);
   __syncthreads();
@@ -232,17 +267,15 @@ k_scatter(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
   for (unsigned c = lane; c < (unsigned)M::B; c += 64) cursor[c] = tile_base[(size_t)tile * M::B + c];
-  const unsigned r0 = fq_locate(rec_start, 0, R - 1, e0);
-  const unsigned r1 = fq_locate(rec_start, 0, R - 1, e1 - 1);
+  SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, e0)};
   __syncthreads();
   for (unsigned eb = e0; eb < e1; eb += 64) {
     const unsigned e = eb + lane;
     const bool valid = e < e1;
-    unsigned ctx = 0, sym = 0;
+    fqgpu_rec rec;
+    unsigned p, ctx = 0, sym = 0;
+    w.locate(eb, e1, e, valid, rec, p);
     if (valid) {
-      const unsigned r = fq_locate(rec_start, r0, r1, e);
-      const fqgpu_rec rec = recs[r];
-      const unsigned p = rec.len - 1u - (e - rec_start[r]);
       fq_sym_ctx<M>(raw, rec, p, ctx, sym);
       sym &= (unsigned)(M::A - 1);
     }
