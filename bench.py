@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--sample-mib", type=int, default=128, help="-S of the reference")
     ap.add_argument("--decode-block-mib", type=int, default=1, help="block size of the many-blocks decode run")
     ap.add_argument("--decode-mib", type=int, default=256, help="data decoded in the many-blocks run")
+    ap.add_argument("--lanes", type=int, default=4, help="blocks in flight per GPU (encode lanes)")
     ap.add_argument("--skip-decode", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     args = ap.parse_args()
@@ -130,6 +131,7 @@ def main():
     blocks = make_workload(F, args.mib << 20, args.block_mib << 20, seed=28 + rank)
     sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
     ctx = F.Context(sft, qft, device=device)
+    ctx.set_lanes(max(1, min(args.lanes, 8)))
     dblocks = [ctx.dblock(raw, recs) for raw, recs in blocks]
     raw_bytes = sum(raw.size for raw, _ in blocks)
     n_recs = sum(len(r) for _, r in blocks)

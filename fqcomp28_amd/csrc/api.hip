@@ -364,6 +364,7 @@ extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsi
     ctx->seg_len = segment;
   }
   ctx->seq_generic = (flags & FQGPU_CHAIN_SEQ_GENERIC) ? 1 : 0;
+  ctx->seq_one_symbol = (flags & FQGPU_CHAIN_SEQ_ONE_SYMBOL) ? 1 : 0;
   return FQGPU_OK;
 }
 

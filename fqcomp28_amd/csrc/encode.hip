@@ -472,6 +472,116 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
   }
 }
 
+// Two symbols per step: T2[s2][s1][x - size] = state after s1 then s2 (16 << log u16 entries,
+// 64 KB at log 11, two workgroups per CU).  Halves the number of dependent LDS reads of a
+// chain; the state between the two symbols is only needed for the emission of the second one
+// and is recomputed off the critical path (by all lanes, from the L1-resident CTable).
+// Workgroups are dispatched longest chain first (order[]), so the longest chain of the block
+// (context 0xD7 also receives the first base of every read) starts immediately.
+__global__ void __launch_bounds__(256)
+k_seq_order(const uint32_t *__restrict__ arrays, uint32_t *__restrict__ order) {
+  __shared__ uint32_t cnt[SeqModel::B];
+  const unsigned c = threadIdx.x;
+  cnt[c] = arrays[c];
+  __syncthreads();
+  const unsigned mine = cnt[c];
+  unsigned rank = 0;
+  for (unsigned o = 0; o < (unsigned)SeqModel::B; o++) rank += (cnt[o] > mine) || (cnt[o] == mine && o < c);
+  order[rank] = c;
+}
+
+__global__ void __launch_bounds__(64)
+k_chain_seq2(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
+             const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ order,
+             const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
+             uint16_t *__restrict__ final_state, StreamResult *res) {
+  extern __shared__ uint32_t lds[];
+  __shared__ uint4 symbuf[SEQ_CHUNK / 16];
+  __shared__ uint16_t statebuf[SEQ_CHUNK / 2];  // (state - size) * 2 in front of every EVEN symbol
+  constexpr unsigned B = SeqModel::B;
+  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
+  const unsigned c = order[blockIdx.x], lane = fq_lane();
+  const unsigned n = ctx_count[c];
+  if (n == 0) return;
+  const uint32_t *tbl = ct + ct_off[c];
+  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
+  const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
+  const uint32_t *tt = tbl + 1 + (size >> 1);
+  unsigned dnb[4];
+  int dfs[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) { dfs[s] = (int)tt[2 * s]; dnb[s] = tt[2 * s + 1]; }
+  // one FSE_encodeSymbol transition on (state - size), straight from the CTable
+  auto step1 = [&](unsigned s, unsigned xi) -> unsigned {
+    const unsigned x = size + xi;
+    const unsigned d = s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3];
+    const int f = s == 0 ? dfs[0] : s == 1 ? dfs[1] : s == 2 ? dfs[2] : dfs[3];
+    const unsigned nb = (x + d) >> 16;
+    return (unsigned)st[(int)(x >> nb) + f] - size;
+  };
+  uint16_t *t2 = reinterpret_cast<uint16_t *>(lds);  // [s2][s1][size], byte offsets of the next lookup
+  for (unsigned e = lane; e < 16 * size; e += 64) {
+    const unsigned xi = e & (size - 1), s1 = (e >> log) & 3u, s2 = e >> (log + 2);
+    t2[e] = (uint16_t)(step1(s2, step1(s1, xi)) * 2u);
+  }
+  const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + ctx_start[c]);  // 16-byte aligned (CTX_PAD)
+  uint4 *gout = reinterpret_cast<uint4 *>(out16 + ctx_start[c]);
+  const char *tbase = reinterpret_cast<const char *>(t2);
+  const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf);
+  unsigned xo = 0;  // (state - size) * 2, meaningful in lane 0 only
+  for (unsigned c0 = 0; c0 < n; c0 += SEQ_CHUNK) {
+    const unsigned len = min(SEQ_CHUNK, n - c0);
+    const unsigned q16 = (len + 15) >> 4;
+    for (unsigned v = lane; v < q16; v += 64) symbuf[v] = gsym[(c0 >> 4) + v];
+    __syncthreads();
+    if (lane == 0) {
+      const unsigned full = len >> 4;
+      for (unsigned g = 0; g < full; g++) {
+        const uint4 sv = symbuf[g];
+        const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {  // pair j = symbols 2j, 2j+1 of the group
+          const unsigned half = w[j >> 1] >> (16 * (j & 1));
+          const unsigned pc = (half & 3u) | ((half >> 6) & 0xCu);  // s1 | s2 << 2
+          statebuf[g * 8 + j] = (uint16_t)xo;
+          xo = *reinterpret_cast<const uint16_t *>(tbase + ((pc << (log + 1)) + xo));
+        }
+      }
+      for (unsigned i = full << 4; i + 1 < len; i += 2) {
+        const unsigned pc = (sbytes[i] & 3u) | ((sbytes[i + 1] & 3u) << 2);
+        statebuf[i >> 1] = (uint16_t)xo;
+        xo = *reinterpret_cast<const uint16_t *>(tbase + ((pc << (log + 1)) + xo));
+      }
+      if (len & 1u) {  // only the last chunk of a chain can be odd
+        statebuf[len >> 1] = (uint16_t)xo;
+        xo = step1(sbytes[len - 1] & 3u, xo >> 1) * 2u;
+      }
+    }
+    __syncthreads();
+    const unsigned q8 = (len + 7) >> 3;
+    for (unsigned v = lane; v < q8; v += 64) {
+      unsigned o[4];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const unsigned i = v * 8 + j;
+        const unsigned s1 = sbytes[i] & 3u, s2 = sbytes[i + 1] & 3u;
+        const unsigned xi1 = (unsigned)statebuf[i >> 1] >> 1;
+        const unsigned xi2 = step1(s1, xi1);  // state between the two symbols
+        const unsigned x1 = size + xi1, x2 = size + xi2;
+        const unsigned nb1 = (x1 + (s1 == 0 ? dnb[0] : s1 == 1 ? dnb[1] : s1 == 2 ? dnb[2] : dnb[3])) >> 16;
+        const unsigned nb2 = (x2 + (s2 == 0 ? dnb[0] : s2 == 1 ? dnb[1] : s2 == 2 ? dnb[2] : dnb[3])) >> 16;
+        o[j >> 1] = ((nb1 << 12) | (x1 & ((1u << nb1) - 1u))) | (((nb2 << 12) | (x2 & ((1u << nb2) - 1u))) << 16);
+      }
+      gout[(c0 >> 3) + v] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    final_state[c] = (uint16_t)(size + (xo >> 1));
+    atomicMax(&res->refixed, n);
+  }
+}
+
 // ------------------------------------------------------------------ K6: bit offsets and packing
 __global__ void __launch_bounds__(PACK_THREADS)
 k_bitcount(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16, unsigned n_sym,
@@ -640,7 +750,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if ((rc = sc.tile_base.reserve((size_t)n_tiles * B * 4))) return rc;
   if ((rc = sc.group_sum.reserve((size_t)n_groups * B * 4))) return rc;
   if ((rc = sc.ctx_arrays.reserve((size_t)(4 * B + 3) * 4))) return rc;
-  if ((rc = sc.seg_state.reserve((size_t)B * 2))) return rc;
+  if ((rc = sc.seg_state.reserve((size_t)B * 2 + (size_t)B * 4))) return rc;
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
   if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
 
@@ -669,7 +779,12 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
-  if (serial_seq) {
+  if (serial_seq && tab.max_log <= 11 && !ctx->seq_one_symbol) {
+    uint32_t *order = reinterpret_cast<uint32_t *>(final_state + B);
+    hipLaunchKernelGGL(k_seq_order, dim3(1), dim3(256), 0, st, arrays, order);
+    hipLaunchKernelGGL(k_chain_seq2, dim3(B), dim3(64), 32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
+                       sc.out16.as<uint16_t>(), arrays, order, tab.ct, tab.ct_off, final_state, res);
+  } else if (serial_seq) {
     hipLaunchKernelGGL(k_chain_seq, dim3(B), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
                        sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, res);
   } else {

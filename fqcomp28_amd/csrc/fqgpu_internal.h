@@ -123,6 +123,7 @@ struct fqgpu_ctx {
   DevTables tab[2];
   unsigned seg_len = 1024;       // nominal segment of the reset-cut chain kernel
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
+  int seq_one_symbol = 0;        // 1: serial sequence kernel with one symbol per step (no T2 table)
   unsigned n_lanes = 4, next_lane = 0;
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch
