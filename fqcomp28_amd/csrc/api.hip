@@ -166,7 +166,7 @@ static void free_lane(EncLane &l) {
   for (DevBuf *b : bufs) b->release();
   for (int s = 0; s < 2; s++) {
     EncScratch &e = l.enc[s];
-    DevBuf *eb[] = {&e.slot_of, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
+    DevBuf *eb[] = {&e.slot_of, &e.keys, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
                     &e.ctx_arrays, &e.seg_state, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
     for (DevBuf *b : eb) b->release();
   }

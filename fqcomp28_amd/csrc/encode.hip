@@ -131,20 +131,22 @@ struct SymbolWalker {
 };
 
 // ------------------------------------------------------------------ K1: per-tile context histogram
+// Also leaves key[e] = ctx | sym << 16 of every symbol in encode order, so that the
+// partition pass is a plain prefetchable linear scan.
 template <class M>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
             const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
-            uint32_t *__restrict__ tile_hist, StreamResult *res) {
+            uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ keys, StreamResult *res) {
   __shared__ uint32_t hist[M::B];
   const unsigned tile = blockIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
   for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x) hist[c] = 0;
   __syncthreads();
-  // every wave takes a contiguous quarter of the tile (multiple of 64 symbols)
+  // every wave takes a contiguous share of the tile (multiple of 64 symbols)
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
-  const unsigned per = (((e1 - e0) + 255u) / 256u) * 64u;
+  const unsigned per = (((e1 - e0) + blockDim.x - 1u) / blockDim.x) * 64u;
   const unsigned wb = min(e0 + wave * per, e1), we = min(wb + per, e1);
   bool bad = false;
   if (wb < we) {
@@ -159,6 +161,7 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
         unsigned ctx, sym;
         fq_sym_ctx<M>(raw, rec, p, ctx, sym);
         bad |= sym >= (unsigned)M::A;
+        keys[e] = ctx | ((sym & (unsigned)(M::A - 1)) << 16);
         atomicAdd(&hist[ctx], 1u);
       }
     }
@@ -258,8 +261,7 @@ k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__
 // context's cursor in LDS.  Stability is what makes every context's run = its chain.
 template <class M>
 __global__ void __launch_bounds__(64)
-k_scatter(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
-          const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
+k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
           const uint32_t *__restrict__ tile_base, uint8_t *__restrict__ sorted_sym,
           uint32_t *__restrict__ slot_of) {
   __shared__ uint32_t cursor[M::B];
@@ -267,18 +269,14 @@ k_scatter(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
   for (unsigned c = lane; c < (unsigned)M::B; c += 64) cursor[c] = tile_base[(size_t)tile * M::B + c];
-  SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, e0)};
+  unsigned key_next = e0 + lane < e1 ? keys[e0 + lane] : 0u;
   __syncthreads();
   for (unsigned eb = e0; eb < e1; eb += 64) {
     const unsigned e = eb + lane;
     const bool valid = e < e1;
-    fqgpu_rec rec;
-    unsigned p, ctx = 0, sym = 0;
-    w.locate(eb, e1, e, valid, rec, p);
-    if (valid) {
-      fq_sym_ctx<M>(raw, rec, p, ctx, sym);
-      sym &= (unsigned)(M::A - 1);
-    }
+    const unsigned key = key_next;
+    key_next = e + 64 < e1 ? keys[e + 64] : 0u;  // in flight while this chunk is ranked
+    const unsigned ctx = key & 0xFFFFu;
     const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
     const unsigned rank = fq_mbcnt(grp);
     const unsigned cur = cursor[ctx];
@@ -286,7 +284,7 @@ k_scatter(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
     if (valid) {
       if (rank == 0) cursor[ctx] = cur + (unsigned)__popcll(grp);
       const unsigned slot = cur + rank;
-      sorted_sym[slot] = (uint8_t)sym;
+      sorted_sym[slot] = (uint8_t)(key >> 16);
       slot_of[e] = slot;
     }
     __syncthreads();
@@ -744,6 +742,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
 
   int rc;
   if ((rc = sc.slot_of.reserve((size_t)n_sym * 4))) return rc;
+  if ((rc = sc.keys.reserve((size_t)n_sym * 4))) return rc;
   if ((rc = sc.sorted_sym.reserve(padded))) return rc;
   if ((rc = sc.out16.reserve(padded * 2))) return rc;
   if ((rc = sc.tile_hist.reserve((size_t)n_tiles * B * 4))) return rc;
@@ -761,8 +760,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   (void)pfx;
 
   FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");
-  hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R,
-                     n_sym, T, sc.tile_hist.as<uint32_t>(), res);
+  hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(M::STREAM ? 1024 : 256), 0, st, b->raw, b->recs,
+                     rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), sc.keys.as<uint32_t>(), res);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");
   hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
@@ -774,9 +773,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.tile_base.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");
-  hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, b->raw, b->recs, rec_start, R,
-                     n_sym, T, sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
-                     sc.slot_of.as<uint32_t>());
+  hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+                     sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
   if (serial_seq && tab.max_log <= 11 && !ctx->seq_one_symbol) {

@@ -91,6 +91,7 @@ struct KernelTimer;  // api.cpp
 // Scratch of the encode pipeline for one stream.
 struct EncScratch {
   DevBuf slot_of;     // u32 [M]   sorted position of every symbol (encode order)
+  DevBuf keys;        // u32 [M]   ctx | sym << 16 of every symbol (encode order)
   DevBuf sorted_sym;  // u8  [M+pad]
   DevBuf out16;       // u16 [M+pad] (nb<<12 | bits) at sorted position
   DevBuf tile_hist;   // u32 [tiles][B]
