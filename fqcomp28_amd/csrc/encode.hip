@@ -265,7 +265,7 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
           const uint32_t *__restrict__ tile_base, uint8_t *__restrict__ sorted_sym,
           uint32_t *__restrict__ slot_of) {
   __shared__ uint32_t cursor[M::B];
-  const unsigned tile = blockIdx.x, lane = threadIdx.x;
+  const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
   for (unsigned c = lane; c < (unsigned)M::B; c += 64) cursor[c] = tile_base[(size_t)tile * M::B + c];
@@ -585,7 +585,8 @@ __global__ void __launch_bounds__(PACK_THREADS)
 k_bitcount(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16, unsigned n_sym,
            uint32_t *__restrict__ tile_bits) {
   __shared__ unsigned wsum[PACK_THREADS / 64];
-  const unsigned e0 = blockIdx.x * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
+  const unsigned ptile = fq_xcd_tile(blockIdx.x, gridDim.x);
+  const unsigned e0 = ptile * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
   unsigned bits = 0;
 #pragma unroll
   for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
@@ -599,7 +600,7 @@ k_bitcount(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ ou
   if (threadIdx.x == 0) {
     unsigned tot = 0;
     for (unsigned i = 0; i < PACK_THREADS / 64; i++) tot += wsum[i];
-    tile_bits[blockIdx.x] = tot;
+    tile_bits[ptile] = tot;
   }
 }
 
@@ -633,8 +634,9 @@ k_pack(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16,
   if (res->overflow) return;
   constexpr unsigned NW = PACK_TILE * 12 / 32 + 4;
   for (unsigned i = threadIdx.x; i < NW; i += PACK_THREADS) words[i] = 0;
-  const unsigned long long b0 = tile_bit_base[blockIdx.x], b1 = tile_bit_base[blockIdx.x + 1];
-  const unsigned e0 = blockIdx.x * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
+  const unsigned ptile = fq_xcd_tile(blockIdx.x, gridDim.x);
+  const unsigned long long b0 = tile_bit_base[ptile], b1 = tile_bit_base[ptile + 1];
+  const unsigned e0 = ptile * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
   unsigned v[PACK_PER_THREAD];
   unsigned bits = 0;
 #pragma unroll

@@ -176,6 +176,16 @@ void fq_timer_span_end(fqgpu_ctx *ctx, hipStream_t st);
 
 __device__ __forceinline__ unsigned fq_lane() { return threadIdx.x & 63u; }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own
+// 4 MiB L2), so with the identity mapping neighbouring tiles never share an L2.  This
+// bijective remap gives every XCD a contiguous range of tiles, walked in order: tiles that
+// run at the same time on one XCD then touch adjacent bytes of every context's run and the
+// partial lines of the permutation passes are completed inside L2 instead of in HBM.
+__device__ __forceinline__ unsigned fq_xcd_tile(unsigned b, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7u, xcd = b & 7u, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+}
+
 // number of set bits of m below the calling lane
 __device__ __forceinline__ unsigned fq_mbcnt(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
