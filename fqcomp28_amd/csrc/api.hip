@@ -8,11 +8,11 @@
 #include <new>
 #include <vector>
 
-// The encode lanes use up to 8 streams (two per block in flight).  ROCm maps streams onto
+// The encode lanes use up to 12 streams (three per block in flight: sequence, quality, long chains).  ROCm maps streams onto
 // GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
-// run back to back; ask for 8 before the runtime initialises (no effect if the host
+// run back to back; ask for 12 before the runtime initialises (no effect if the host
 // application already initialised HIP or set the variable itself).
-__attribute__((constructor)) static void fq_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void fq_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_hip_msg[256] = "";
@@ -154,8 +154,11 @@ EncLane *fq_next_lane(fqgpu_ctx *ctx) {
   if (!l.st_seq) {
     if (hipStreamCreateWithFlags(&l.st_seq, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&l.st_qual, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&l.st_hot, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&l.ev_scat, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&l.ev_hot, hipEventDisableTiming) != hipSuccess)
       return nullptr;
   }
   return &l;
@@ -170,10 +173,10 @@ static void free_lane(EncLane &l) {
                     &e.ctx_arrays, &e.seg_state, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
     for (DevBuf *b : eb) b->release();
   }
-  if (l.ev_fork) (void)hipEventDestroy(l.ev_fork);
-  if (l.ev_join) (void)hipEventDestroy(l.ev_join);
-  if (l.st_seq) (void)hipStreamDestroy(l.st_seq);
-  if (l.st_qual) (void)hipStreamDestroy(l.st_qual);
+  hipEvent_t evs[] = {l.ev_fork, l.ev_join, l.ev_scat, l.ev_hot};
+  for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+  hipStream_t sts[] = {l.st_seq, l.st_qual, l.st_hot};
+  for (hipStream_t q : sts) if (q) (void)hipStreamDestroy(q);
   l = EncLane();
 }
 
@@ -475,6 +478,7 @@ extern "C" int fqgpu_sync(fqgpu_ctx *ctx) {
   for (int i = 0; i < FQ_MAX_LANES; i++) {
     if (ctx->lanes[i].st_seq) FQ_HIP(hipStreamSynchronize(ctx->lanes[i].st_seq));
     if (ctx->lanes[i].st_qual) FQ_HIP(hipStreamSynchronize(ctx->lanes[i].st_qual));
+    if (ctx->lanes[i].st_hot) FQ_HIP(hipStreamSynchronize(ctx->lanes[i].st_hot));
   }
   if (ctx->stream) FQ_HIP(hipStreamSynchronize(ctx->stream));
   return FQGPU_OK;

@@ -394,9 +394,9 @@ constexpr unsigned SEQ_CHUNK = 4096;
 
 __global__ void __launch_bounds__(64)
 k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-            const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
-            const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state,
-            StreamResult *res) {
+            const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ rank_of, unsigned n_sym,
+            const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
+            uint16_t *__restrict__ final_state, StreamResult *res) {
   extern __shared__ uint32_t lds[];
   __shared__ uint4 symbuf[SEQ_CHUNK / 16];
   __shared__ uint16_t statebuf[SEQ_CHUNK];  // (state - size) * 2 in front of every symbol
@@ -405,6 +405,7 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
   const unsigned c = blockIdx.x, lane = fq_lane();
   const unsigned n = ctx_count[c];
   if (n == 0) return;
+  if (rank_of && seq_chain_is_hot(n, rank_of[c], n_sym)) return;  // k_chain_seq2 walks this one
   const uint32_t *tbl = ct + ct_off[c];
   const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
   const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
@@ -476,6 +477,13 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
 // and is recomputed off the critical path (by all lanes, from the L1-resident CTable).
 // Workgroups are dispatched longest chain first (order[]), so the longest chain of the block
 // (context 0xD7 also receives the first base of every read) starts immediately.
+constexpr unsigned SEQ_HOT_MAX = 16;  // at most this many chains per block take the two-symbol kernel
+
+// a chain is "hot" when it is among the SEQ_HOT_MAX longest and 25 % above the average length
+__device__ __forceinline__ bool seq_chain_is_hot(unsigned n, unsigned rank, unsigned n_sym) {
+  return rank < SEQ_HOT_MAX && (unsigned long long)n * 4ull * SeqModel::B > (unsigned long long)n_sym * 5ull;
+}
+
 __global__ void __launch_bounds__(256)
 k_seq_order(const uint32_t *__restrict__ arrays, uint32_t *__restrict__ order) {
   __shared__ uint32_t cnt[SeqModel::B];
@@ -486,11 +494,12 @@ k_seq_order(const uint32_t *__restrict__ arrays, uint32_t *__restrict__ order) {
   unsigned rank = 0;
   for (unsigned o = 0; o < (unsigned)SeqModel::B; o++) rank += (cnt[o] > mine) || (cnt[o] == mine && o < c);
   order[rank] = c;
+  order[SeqModel::B + c] = rank;  // rank_of
 }
 
 __global__ void __launch_bounds__(64)
 k_chain_seq2(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-             const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ order,
+             const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ order, unsigned n_sym,
              const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
              uint16_t *__restrict__ final_state, StreamResult *res) {
   extern __shared__ uint32_t lds[];
@@ -500,7 +509,7 @@ k_chain_seq2(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out1
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
   const unsigned c = order[blockIdx.x], lane = fq_lane();
   const unsigned n = ctx_count[c];
-  if (n == 0) return;
+  if (n == 0 || !seq_chain_is_hot(n, blockIdx.x, n_sym)) return;
   const uint32_t *tbl = ct + ct_off[c];
   const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
   const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
@@ -751,7 +760,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if ((rc = sc.tile_base.reserve((size_t)n_tiles * B * 4))) return rc;
   if ((rc = sc.group_sum.reserve((size_t)n_groups * B * 4))) return rc;
   if ((rc = sc.ctx_arrays.reserve((size_t)(4 * B + 3) * 4))) return rc;
-  if ((rc = sc.seg_state.reserve((size_t)B * 2 + (size_t)B * 4))) return rc;
+  if ((rc = sc.seg_state.reserve((size_t)B * 2 + (size_t)B * 8))) return rc;
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
   if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
 
@@ -780,13 +789,25 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
   if (serial_seq && tab.max_log <= 11 && !ctx->seq_one_symbol) {
+    // the few long chains: two symbols per step (64 KB table each) on the lane's third stream,
+    // everything else: one symbol per step (16 KB table) here -- both kernels run side by side
     uint32_t *order = reinterpret_cast<uint32_t *>(final_state + B);
     hipLaunchKernelGGL(k_seq_order, dim3(1), dim3(256), 0, st, arrays, order);
-    hipLaunchKernelGGL(k_chain_seq2, dim3(B), dim3(64), 32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
-                       sc.out16.as<uint16_t>(), arrays, order, tab.ct, tab.ct_off, final_state, res);
+    FQ_HIP(hipEventRecord(lane.ev_scat, st));
+    FQ_HIP(hipStreamWaitEvent(lane.st_hot, lane.ev_scat, 0));
+    fq_timer_span_begin(ctx, "seq.chains.hot", lane.st_hot);
+    hipLaunchKernelGGL(k_chain_seq2, dim3(SEQ_HOT_MAX), dim3(64), 32u << tab.max_log, lane.st_hot,
+                       sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, order, n_sym, tab.ct,
+                       tab.ct_off, final_state, res);
+    fq_timer_span_end(ctx, lane.st_hot);
+    FQ_HIP(hipEventRecord(lane.ev_hot, lane.st_hot));
+    hipLaunchKernelGGL(k_chain_seq, dim3(B), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
+                       sc.out16.as<uint16_t>(), arrays, order + B, n_sym, tab.ct, tab.ct_off, final_state, res);
+    FQ_HIP(hipStreamWaitEvent(st, lane.ev_hot, 0));
   } else if (serial_seq) {
     hipLaunchKernelGGL(k_chain_seq, dim3(B), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
-                       sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, res);
+                       sc.out16.as<uint16_t>(), arrays, (const uint32_t *)nullptr, n_sym, tab.ct, tab.ct_off,
+                       final_state, res);
   } else {
     hipLaunchKernelGGL(k_chains_reset<M>, dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                        sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, res);
