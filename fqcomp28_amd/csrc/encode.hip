@@ -391,6 +391,13 @@ k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ ou
 // front of every symbol; then all 64 lanes turn (state, symbol) into the packed (nb, bits)
 // outputs in parallel and store them coalesced.  The chain lane never waits on global memory.
 constexpr unsigned SEQ_CHUNK = 4096;
+constexpr unsigned SEQ_HOT_MAX = 16;  // at most this many chains per block take the two-symbol kernel
+
+// a chain is "hot" when it is among the SEQ_HOT_MAX longest and 25 % above the average length
+__device__ __forceinline__ bool seq_chain_is_hot(unsigned n, unsigned rank, unsigned n_sym) {
+  return rank < SEQ_HOT_MAX && (unsigned long long)n * 4ull * SeqModel::B > (unsigned long long)n_sym * 5ull;
+}
+
 
 __global__ void __launch_bounds__(64)
 k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
@@ -477,13 +484,6 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
 // and is recomputed off the critical path (by all lanes, from the L1-resident CTable).
 // Workgroups are dispatched longest chain first (order[]), so the longest chain of the block
 // (context 0xD7 also receives the first base of every read) starts immediately.
-constexpr unsigned SEQ_HOT_MAX = 16;  // at most this many chains per block take the two-symbol kernel
-
-// a chain is "hot" when it is among the SEQ_HOT_MAX longest and 25 % above the average length
-__device__ __forceinline__ bool seq_chain_is_hot(unsigned n, unsigned rank, unsigned n_sym) {
-  return rank < SEQ_HOT_MAX && (unsigned long long)n * 4ull * SeqModel::B > (unsigned long long)n_sym * 5ull;
-}
-
 __global__ void __launch_bounds__(256)
 k_seq_order(const uint32_t *__restrict__ arrays, uint32_t *__restrict__ order) {
   __shared__ uint32_t cnt[SeqModel::B];
