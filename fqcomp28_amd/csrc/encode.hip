@@ -395,6 +395,7 @@ constexpr unsigned SEQ_HOT_MAX = 16;  // at most this many chains per block take
 
 // a chain is "hot" when it is among the SEQ_HOT_MAX longest and 25 % above the average length
 __device__ __forceinline__ bool seq_chain_is_hot(unsigned n, unsigned rank, unsigned n_sym) {
+  if (n_sym == 0) return true;  // "every chain takes the two-symbol kernel" mode
   return rank < SEQ_HOT_MAX && (unsigned long long)n * 4ull * SeqModel::B > (unsigned long long)n_sym * 5ull;
 }
 
@@ -788,7 +789,12 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
-  if (serial_seq && tab.max_log <= 11 && !ctx->seq_one_symbol) {
+  if (serial_seq && tab.max_log <= 11 && ctx->seq_all_t2) {
+    uint32_t *order = reinterpret_cast<uint32_t *>(final_state + B);
+    hipLaunchKernelGGL(k_seq_order, dim3(1), dim3(256), 0, st, arrays, order);
+    hipLaunchKernelGGL(k_chain_seq2, dim3(B), dim3(64), 32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
+                       sc.out16.as<uint16_t>(), arrays, order, 0u, tab.ct, tab.ct_off, final_state, res);
+  } else if (serial_seq && tab.max_log <= 11 && !ctx->seq_one_symbol) {
     // the few long chains: two symbols per step (64 KB table each) on the lane's third stream,
     // everything else: one symbol per step (16 KB table) here -- both kernels run side by side
     uint32_t *order = reinterpret_cast<uint32_t *>(final_state + B);

@@ -91,6 +91,7 @@ void fqgpu_ctx_destroy(fqgpu_ctx *ctx);
  * FQGPU_CHAIN_SEQ_ONE_SYMBOL or when a table log exceeds 11). */
 #define FQGPU_CHAIN_SEQ_GENERIC 1u
 #define FQGPU_CHAIN_SEQ_ONE_SYMBOL 2u /* serial sequence kernel without the two-symbol table */
+#define FQGPU_CHAIN_SEQ_ALL_TWO_SYMBOL 4u /* two-symbol table for every sequence chain, not only the long ones */
 int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned flags);
 /* Number of blocks the handle keeps in flight (encode lanes, 1..8, default 4): each
  * fqgpu_dblock_encode goes to the next lane (own HIP streams and scratch). */
