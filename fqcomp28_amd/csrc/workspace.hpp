@@ -1,0 +1,202 @@
+// workspace.hpp -- the reference's block-codec surface on top of the fqgpu C ABI.
+//
+// Mirrors, name for name, what the reference exposes for this path so that its pipeline
+// (src/process.cpp:46-68, 93-104) and its tests read the same:
+//   FastqRecord / FastqChunk                       src/defs.h:22-52
+//   CompressedBuffersDst / CompressedBuffersSrc    src/compressed_buffers.h:34-101
+//   DatasetMeta (ft_seq / ft_qual part)            src/prepare.h:14-57
+//   CompressionWorkspace::encodeChunk              src/workspace.h:69,  src/workspace.cpp:14-45
+//   DecompressionWorkspace::decodeChunk            src/workspace.h:112, src/workspace.cpp:47-88
+//   Workspace::compressBoundSequence/Quality       src/workspace.h:21-35
+//   FSE_{Sequence,Quality}::calculateFreqTable     src/fse_sequence.h:72, src/fse_quality.h:50
+// Only the seq/qual FSE part of a block is coded here (header tokeniser and
+// the libbsc pass over the misc streams stay with the host application).  Error behaviour:
+// the reference asserts / silently returns size 0; this shim throws std::runtime_error with
+// fqgpu_strerror().  Header-only; link with libfqgpu.so.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "../../include/fqgpu.h"
+
+namespace fqcomp28 {
+
+using readlen_t = uint16_t;  // src/defs.h:14
+using FastqData = std::vector<char>;
+
+/** Non-owning - holds pointers into outside allocated data (src/defs.h:22-32) */
+struct FastqRecord {
+  char *seqp = nullptr, *qualp = nullptr, *headerp = nullptr;
+  readlen_t length = 0, header_length = 0;
+  [[nodiscard]] std::string_view header() const { return {headerp, header_length}; }
+  [[nodiscard]] std::string_view seq() const { return {seqp, length}; }
+  [[nodiscard]] std::string_view qual() const { return {qualp, length}; }
+};
+
+struct FastqChunk {  // src/defs.h:34-52
+  FastqData raw_data;
+  std::vector<FastqRecord> records;
+  std::size_t tot_reads_length = 0;
+  std::size_t headers_length = 0;
+  unsigned idx = 0;
+  void clear() {
+    idx = 0; tot_reads_length = 0; headers_length = 0;
+    raw_data.clear(); records.clear();
+  }
+};
+
+struct cb_original_sizes_t {  // src/compressed_buffers.h:10-32 (header fields left to the host)
+  uint32_t total = 0, readlens = 0, n_records = 0, n_count = 0, n_pos = 0;
+};
+
+struct CompressedBuffers {  // src/compressed_buffers.h:34-69
+  std::vector<std::byte> seq, qual, readlens, n_count, n_pos;
+  cb_original_sizes_t original_size;
+  uint32_t chunk_idx = 0;
+  /* like the reference, clear() does NOT clear n_count / n_pos */
+  virtual void clear() { seq.clear(); qual.clear(); readlens.clear(); original_size = {}; }
+  virtual ~CompressedBuffers() = default;
+};
+struct CompressedBuffersDst : CompressedBuffers {};
+struct CompressedBuffersSrc : CompressedBuffers {
+  struct { std::size_t n_count = 0, n_pos = 0; } index;  // src/compressed_buffers.h:90-93
+  void clear() override { CompressedBuffers::clear(); index = {}; }
+};
+
+inline void fqgpuCheck(int rc, const char *what) {
+  if (rc != FQGPU_OK) throw std::runtime_error(std::string(what) + ": " + fqgpu_strerror(rc));
+}
+
+/** FreqTable PODs exactly as the archive stores them (src/fse_common.hpp:147-174) */
+struct DatasetMeta {
+  std::unique_ptr<std::byte[]> ft_seq{new std::byte[FQGPU_SEQ_FT_BYTES]};
+  std::unique_ptr<std::byte[]> ft_qual{new std::byte[FQGPU_QUAL_FT_BYTES]};
+  DatasetMeta() = default;
+  /** DatasetMeta(const FastqChunk&) (src/prepare.h:23-27): dataset analysis on the GPU */
+  explicit DatasetMeta(const FastqChunk &chunk, int device = 0) {
+    std::vector<fqgpu_rec> recs = toRecordTable(chunk);
+    fqgpuCheck(fqgpu_freq_tables(device, reinterpret_cast<const uint8_t *>(chunk.raw_data.data()),
+                                 chunk.raw_data.size(), recs.data(), recs.size(), ft_seq.get(),
+                                 ft_qual.get(), nullptr, nullptr),
+               "calculateFreqTable");
+  }
+  static std::vector<fqgpu_rec> toRecordTable(const FastqChunk &chunk) {
+    std::vector<fqgpu_rec> recs(chunk.records.size());
+    const char *base = chunk.raw_data.data();
+    for (std::size_t i = 0; i < recs.size(); ++i) {
+      const FastqRecord &r = chunk.records[i];
+      recs[i] = {static_cast<uint32_t>(r.seqp - base), static_cast<uint32_t>(r.qualp - base), r.length};
+    }
+    return recs;
+  }
+};
+
+class Workspace {
+public:
+  static std::size_t compressBoundSequence(std::size_t n) { return fqgpu_bound_seq(n); }
+  static std::size_t compressBoundQuality(std::size_t n) { return fqgpu_bound_qual(n); }
+
+protected:
+  explicit Workspace(const DatasetMeta *meta, int device) : meta_(meta) {
+    fqgpuCheck(fqgpu_ctx_create(device, meta->ft_seq.get(), meta->ft_qual.get(), &ctx_), "Workspace");
+  }
+  ~Workspace() { fqgpu_ctx_destroy(ctx_); }
+  Workspace(const Workspace &) = delete;
+  Workspace &operator=(const Workspace &) = delete;
+  const DatasetMeta *const meta_;
+  fqgpu_ctx *ctx_ = nullptr;
+};
+
+class CompressionWorkspace : public Workspace {
+public:
+  explicit CompressionWorkspace(const DatasetMeta *meta, int device = 0) : Workspace(meta, device) {}
+
+  /** Encodes reads into cbs, allocating memory in cbs as needed; mutates the chunk (N -> A) */
+  void encodeChunk(FastqChunk &chunk, CompressedBuffersDst &cbs) {
+    cbs.clear();
+    cbs.chunk_idx = chunk.idx;
+    const std::size_t R = chunk.records.size();
+    cbs.seq.resize(compressBoundSequence(chunk.tot_reads_length));
+    cbs.qual.resize(compressBoundQuality(chunk.tot_reads_length));
+    cbs.readlens.resize(R * sizeof(readlen_t));
+    std::vector<fqgpu_rec> recs = DatasetMeta::toRecordTable(chunk);
+    std::vector<uint16_t> n_count(R), n_pos(chunk.tot_reads_length);
+    std::size_t seq_len = 0, qual_len = 0, n_pos_len = 0;
+    fqgpuCheck(fqgpu_encode_block(ctx_, reinterpret_cast<uint8_t *>(chunk.raw_data.data()),
+                                  chunk.raw_data.size(), recs.data(), R,
+                                  reinterpret_cast<uint8_t *>(cbs.seq.data()), cbs.seq.size(), &seq_len,
+                                  reinterpret_cast<uint8_t *>(cbs.qual.data()), cbs.qual.size(), &qual_len,
+                                  reinterpret_cast<uint16_t *>(cbs.readlens.data()), n_count.data(),
+                                  n_pos.data(), n_pos.size(), &n_pos_len, FQGPU_F_WRITE_BACK_N),
+               "encodeChunk");
+    cbs.seq.resize(seq_len);
+    cbs.qual.resize(qual_len);
+    // appended, never cleared: what a reused CompressedBuffersDst holds in the reference
+    append(cbs.n_count, n_count.data(), R);
+    append(cbs.n_pos, n_pos.data(), n_pos_len);
+    cbs.original_size.n_records = static_cast<uint32_t>(R);
+    cbs.original_size.total = static_cast<uint32_t>(chunk.raw_data.size());
+    cbs.original_size.readlens = static_cast<uint32_t>(cbs.readlens.size());
+    cbs.original_size.n_count = static_cast<uint32_t>(cbs.n_count.size());
+    cbs.original_size.n_pos = static_cast<uint32_t>(cbs.n_pos.size());
+  }
+
+private:
+  static void append(std::vector<std::byte> &dst, const uint16_t *src, std::size_t n) {
+    const std::size_t old = dst.size();
+    dst.resize(old + n * sizeof(uint16_t));
+    std::memcpy(dst.data() + old, src, n * sizeof(uint16_t));
+  }
+};
+
+class DecompressionWorkspace : public Workspace {
+public:
+  explicit DecompressionWorkspace(const DatasetMeta *meta, int device = 0) : Workspace(meta, device) {}
+
+  /** Second pass of decodeChunk: chunk.raw_data / chunk.records have been laid out by the
+   *  host's first pass (headers decoded, seqp/qualp/length set: src/workspace.cpp:62-80) */
+  void decodeChunk(FastqChunk &chunk, CompressedBuffersSrc &cbs) {
+    std::vector<fqgpu_rec> recs = DatasetMeta::toRecordTable(chunk);
+    fqgpuCheck(fqgpu_decode_block(ctx_, reinterpret_cast<const uint8_t *>(cbs.seq.data()), cbs.seq.size(),
+                                  reinterpret_cast<const uint8_t *>(cbs.qual.data()), cbs.qual.size(),
+                                  reinterpret_cast<const uint16_t *>(cbs.n_count.data()),
+                                  cbs.index.n_count / sizeof(uint16_t),
+                                  reinterpret_cast<const uint16_t *>(cbs.n_pos.data()),
+                                  cbs.index.n_pos / sizeof(uint16_t), recs.data(), recs.size(),
+                                  reinterpret_cast<uint8_t *>(chunk.raw_data.data()), chunk.raw_data.size()),
+               "decodeChunk");
+  }
+};
+
+/** FastqReader::parseRecords (src/fastq_io.cpp:67-125) on top of fqgpu_parse_fastq */
+inline std::size_t parseRecords(FastqChunk &chunk) {
+  const auto *raw = reinterpret_cast<const uint8_t *>(chunk.raw_data.data());
+  const long n = fqgpu_parse_fastq(raw, chunk.raw_data.size(), nullptr, 0);
+  if (n < 0) throw std::invalid_argument("malformed FASTQ block");
+  std::vector<fqgpu_rec> recs(static_cast<std::size_t>(n));
+  fqgpu_parse_fastq(raw, chunk.raw_data.size(), recs.data(), recs.size());
+  chunk.records.resize(recs.size());
+  char *base = chunk.raw_data.data();
+  std::size_t prev_end = 0;
+  for (std::size_t i = 0; i < recs.size(); ++i) {
+    FastqRecord &r = chunk.records[i];
+    r.headerp = base + prev_end;
+    r.header_length = static_cast<readlen_t>(recs[i].seq_off - 1 - prev_end);
+    r.seqp = base + recs[i].seq_off;
+    r.qualp = base + recs[i].qual_off;
+    r.length = static_cast<readlen_t>(recs[i].len);
+    chunk.tot_reads_length += r.length;
+    chunk.headers_length += r.header_length;
+    prev_end = recs[i].qual_off + recs[i].len + 1;
+  }
+  return prev_end;
+}
+
+}  // namespace fqcomp28

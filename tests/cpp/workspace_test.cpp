@@ -1,0 +1,90 @@
+// The reference's hot-path tests restated against the drop-in shim
+// (reference test/workspace_test.cpp:45-69 "Workspace::encodeChunk",
+//  test/fse_sequence_test.cpp:17-50, test/fse_quality_test.cpp:17-49: all round-trips).
+// Usage: workspace_test <fastq> [<fastq> ...]   (needs a GPU)
+#include "../../fqcomp28_amd/csrc/workspace.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+
+using namespace fqcomp28;
+
+static FastqChunk loadFastqFileContents(const char *path) {  // test/test_utils.cpp:21-26
+  FastqChunk chunk;
+  std::ifstream ifs(path, std::ios::binary);
+  chunk.raw_data.assign(std::istreambuf_iterator<char>(ifs), std::istreambuf_iterator<char>());
+  parseRecords(chunk);
+  return chunk;
+}
+
+static CompressedBuffersSrc convertToSrcBuffers(CompressedBuffersDst &&in) {  // test/test_utils.h:27-48
+  CompressedBuffersSrc src;
+  src.original_size = in.original_size;
+  src.seq = std::move(in.seq);
+  src.qual = std::move(in.qual);
+  src.n_count = std::move(in.n_count);
+  src.index.n_count = src.n_count.size();
+  src.n_pos = std::move(in.n_pos);
+  src.index.n_pos = src.n_pos.size();
+  src.readlens = std::move(in.readlens);
+  return src;
+}
+
+#define CHECK(x) do { if (!(x)) { std::printf("CHECK failed: %s (%s:%d)\n", #x, __FILE__, __LINE__); return 1; } } while (0)
+
+static int encodeChunkRoundTrip(const char *path) {
+  FastqChunk chunk_in = loadFastqFileContents(path);
+  const FastqData original = chunk_in.raw_data;
+  const DatasetMeta meta(chunk_in);
+  CompressionWorkspace cwksp(&meta);
+  DecompressionWorkspace dwksp(&meta);
+  CompressedBuffersDst cbs;
+
+  // a reused buffer set: the second encode appends to n_count / n_pos
+  for (int pass = 0; pass < 2; ++pass) {
+    chunk_in.raw_data = original;
+    cwksp.encodeChunk(chunk_in, cbs);
+  }
+  CHECK(cbs.seq.size() <= Workspace::compressBoundSequence(chunk_in.tot_reads_length));
+  CHECK(cbs.n_count.size() == 2 * chunk_in.records.size() * sizeof(readlen_t));
+
+  // first pass of decodeChunk (host side): skeleton with headers, '+' and newlines
+  FastqChunk chunk_out;
+  chunk_out.raw_data = original;
+  parseRecords(chunk_out);
+  for (auto &r : chunk_out.records) {
+    std::memset(r.seqp, '?', r.length);
+    std::memset(r.qualp, '?', r.length);
+  }
+  CompressedBuffersSrc src = convertToSrcBuffers(std::move(cbs));
+  dwksp.decodeChunk(chunk_out, src);
+
+  CHECK(chunk_out.records.size() == chunk_in.records.size());
+  FastqChunk ref;
+  ref.raw_data = original;
+  parseRecords(ref);
+  for (std::size_t i = 0, E = ref.records.size(); i < E; ++i) {
+    CHECK(ref.records[i].header() == chunk_out.records[i].header());
+    CHECK(ref.records[i].seq() == chunk_out.records[i].seq());
+    CHECK(ref.records[i].qual() == chunk_out.records[i].qual());
+  }
+  CHECK(chunk_out.raw_data == original);
+  std::printf("ok %s: %zu records, seq %zu B, qual %zu B\n", path, ref.records.size(), src.seq.size(),
+              src.qual.size());
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (fqgpu_device_count() < 1) { std::printf("no GPU: the shim has no CPU fallback\n"); return 2; }
+  int bad = 0;
+  for (int i = 1; i < argc; ++i) {
+    try {
+      bad += encodeChunkRoundTrip(argv[i]);
+    } catch (const std::exception &e) {
+      std::printf("exception on %s: %s\n", argv[i], e.what());
+      bad++;
+    }
+  }
+  return bad ? 1 : 0;
+}

@@ -356,3 +356,19 @@ def test_full_size_roundtrip_1gib(F):
         b.close()
     ctx.close()
     assert total > (1 << 30) - 16 * 400
+
+
+# ---------------------------------------------------------------- the C++ drop-in shim
+def test_cpp_workspace_shim_roundtrip(golden_dir):
+    """fqcomp28_amd/csrc/workspace.hpp (the reference's Workspace/CompressedBuffers surface over the
+    C ABI): the reference's own Workspace::encodeChunk round-trip test, restated in C++."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "workspace_test")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(root, "tests", "cpp", "workspace_test.cpp"),
+                    "-L" + os.path.join(root, "fqcomp28_amd"), "-lfqgpu",
+                    "-Wl,-rpath," + os.path.join(root, "fqcomp28_amd")], check=True)
+    files = [os.path.join(golden_dir, f + ".fastq") for f in FIXTURES]
+    out = subprocess.run([exe] + files, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok ") == len(files)
