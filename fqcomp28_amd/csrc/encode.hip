@@ -372,13 +372,58 @@ k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ ou
     }
     if (!found) return;
   }
+  // The walk, 16 symbols per 16-byte load and two 16-byte stores per full group (the run of
+  // a context is 16-byte aligned); only the ragged head and tail of a piece use 2-byte stores.
   unsigned steps = 0;
-  for (;;) {
+  bool done = false;
+  // head: up to the next multiple of 16
+  while (!done && (i & 15u)) {
     const unsigned sy = sym[i];
     out[i] = (uint16_t)chain_step(t, x, sy);
     i++; steps++;
-    if (i >= n) { final_state[c] = (uint16_t)x; break; }
-    if (i >= end && is_reset_symbol(t, sy)) break;  // the lane of a later segment starts here
+    if (i >= n) { final_state[c] = (uint16_t)x; done = true; }
+    else if (i >= end && is_reset_symbol(t, sy)) done = true;
+  }
+  if (!done) {
+    const uint4 *sym16 = reinterpret_cast<const uint4 *>(sym);
+    uint4 *out16v = reinterpret_cast<uint4 *>(out);
+    uint4 cur = sym16[i >> 4];
+    while (!done && i + 16 <= n) {
+      const uint4 nxt = (i + 32 <= n + 15u) ? sym16[(i >> 4) + 1] : cur;  // padded run: safe to read
+      const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+      unsigned o[8];
+      int stop_at = -1;  // index inside the group after which this lane's piece ends
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        if (stop_at < 0) {  // predicated, no break: keeps o[] and w[] in registers
+          const unsigned sy = (w[j >> 2] >> (8 * (j & 3))) & (unsigned)(M::A - 1);
+          const unsigned v = chain_step(t, x, sy);
+          if (j & 1) o[j >> 1] |= v << 16; else o[j >> 1] = v;
+          if (i + j + 1 >= end && i + j + 1 < n && is_reset_symbol(t, sy)) stop_at = j;
+        }
+      }
+      if (stop_at < 0) {
+        out16v[i >> 3] = make_uint4(o[0], o[1], o[2], o[3]);
+        out16v[(i >> 3) + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+        i += 16; steps += 16;
+        cur = nxt;
+      } else {  // the next lane starts inside this group: commit only our symbols
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+          if (j <= stop_at) out[i + j] = (uint16_t)(o[j >> 1] >> (16 * (j & 1)));
+        i += (unsigned)stop_at + 1; steps += (unsigned)stop_at + 1;
+        done = true;
+      }
+    }
+    if (!done && i >= n) { final_state[c] = (uint16_t)x; done = true; }
+    // tail: fewer than 16 symbols left in the chain
+    while (!done) {
+      const unsigned sy = sym[i];
+      out[i] = (uint16_t)chain_step(t, x, sy);
+      i++; steps++;
+      if (i >= n) { final_state[c] = (uint16_t)x; done = true; }
+      else if (i >= end && is_reset_symbol(t, sy)) done = true;
+    }
   }
   atomicMax(&res->refixed, steps);  // longest serial run (diagnostic)
 }
