@@ -484,15 +484,22 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
     __syncthreads();
     if (lane == 0) {
       const unsigned full = len >> 4;
+      uint4 *state4 = reinterpret_cast<uint4 *>(statebuf);
+      uint4 sv = symbuf[0];
       for (unsigned g = 0; g < full; g++) {
-        const uint4 sv = symbuf[g];
+        const uint4 sv_next = symbuf[g + 1 < q16 ? g + 1 : g];  // lands while this group is walked
         const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
+        unsigned xs[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
           const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & 3u;
-          statebuf[g * 16 + j] = (uint16_t)xo;
+          xs[j] = xo;
           xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
         }
+        // 16 states leave as two 16-byte LDS writes instead of sixteen 2-byte ones
+        state4[2 * g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
+        state4[2 * g + 1] = make_uint4(xs[8] | (xs[9] << 16), xs[10] | (xs[11] << 16), xs[12] | (xs[13] << 16), xs[14] | (xs[15] << 16));
+        sv = sv_next;
       }
       for (unsigned i = full << 4; i < len; i++) {
         const unsigned s = sbytes[i] & 3u;
@@ -589,16 +596,21 @@ k_chain_seq2(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out1
     __syncthreads();
     if (lane == 0) {
       const unsigned full = len >> 4;
+      uint4 *state4 = reinterpret_cast<uint4 *>(statebuf);
+      uint4 sv = symbuf[0];
       for (unsigned g = 0; g < full; g++) {
-        const uint4 sv = symbuf[g];
+        const uint4 sv_next = symbuf[g + 1 < q16 ? g + 1 : g];  // lands while this group is walked
         const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
+        unsigned xs[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {  // pair j = symbols 2j, 2j+1 of the group
           const unsigned half = w[j >> 1] >> (16 * (j & 1));
           const unsigned pc = (half & 3u) | ((half >> 6) & 0xCu);  // s1 | s2 << 2
-          statebuf[g * 8 + j] = (uint16_t)xo;
+          xs[j] = xo;
           xo = *reinterpret_cast<const uint16_t *>(tbase + ((pc << (log + 1)) + xo));
         }
+        state4[g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
+        sv = sv_next;
       }
       for (unsigned i = full << 4; i + 1 < len; i += 2) {
         const unsigned pc = (sbytes[i] & 3u) | ((sbytes[i + 1] & 3u) << 2);
