@@ -428,13 +428,16 @@ k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ ou
   atomicMax(&res->refixed, steps);  // longest serial run (diagnostic)
 }
 
-// Sequence chains: one wave per context.  A chain step on the critical path is one add and
-// one 2-byte LDS read (measured 62.5 shader cycles = 26 ns, tools/chain_ubench.hip): the
-// transition table is expanded to next[s][x - size] in LDS (4 << log u16 entries, pre-scaled
-// to byte offsets).  Per SEQ_CHUNK symbols: the wave stages the symbols into LDS with
-// coalesced 16-byte loads; lane 0 walks the chain LDS -> LDS and records only the state in
-// front of every symbol; then all 64 lanes turn (state, symbol) into the packed (nb, bits)
-// outputs in parallel and store them coalesced.  The chain lane never waits on global memory.
+// Sequence chains: one workgroup of two waves per context.  A chain step on the critical path
+// is one add and one 2-byte LDS read (measured 62.5 shader cycles = 26 ns,
+// tools/chain_ubench.hip): the transition table is expanded to next[s][x - size] in LDS
+// (4 << log u16 entries, pre-scaled to byte offsets).  Software pipeline over chunks of
+// SEQ_CHUNK symbols, double-buffered in LDS:
+//   wave 0, lane 0 : walks chunk k LDS -> LDS, recording only the state in front of every symbol
+//   wave 1         : turns (state, symbol) of chunk k-1 into the packed (nb, bits) outputs and
+//                    stores them with coalesced 16-byte stores, then stages the symbols of
+//                    chunk k+1 with coalesced 16-byte loads
+// so the chain lane never waits on global memory and never computes an output.
 constexpr unsigned SEQ_CHUNK = 4096;
 constexpr unsigned SEQ_HOT_MAX = 16;  // at most this many chains per block take the two-symbol kernel
 
@@ -444,99 +447,152 @@ __device__ __forceinline__ bool seq_chain_is_hot(unsigned n, unsigned rank, unsi
   return rank < SEQ_HOT_MAX && (unsigned long long)n * 4ull * SeqModel::B > (unsigned long long)n_sym * 5ull;
 }
 
+// (state, symbol) -> (nb << 12 | low nb bits of the state) for 8 consecutive symbols of a
+// chunk; states come from statebuf (every symbol: STRIDE 1; every even symbol: STRIDE 2, the
+// odd ones are recomputed through the one-symbol table `next`)
+template <int STRIDE>
+__device__ __forceinline__ uint4 seq_outputs8(const uint8_t *sbytes, const uint16_t *statebuf, const char *nbase,
+                                              unsigned v, unsigned log, unsigned size, const unsigned *dnb) {
+  unsigned o[4];
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const unsigned i = v * 8 + j;
+    const unsigned s1 = sbytes[i] & 3u, s2 = sbytes[i + 1] & 3u;
+    const unsigned xo1 = statebuf[STRIDE == 1 ? i : (i >> 1)];
+    const unsigned xo2 = STRIDE == 1 ? (unsigned)statebuf[i + 1]
+                                     : (unsigned)*reinterpret_cast<const uint16_t *>(nbase + ((s1 << (log + 1)) + xo1));
+    const unsigned x1 = size + (xo1 >> 1), x2 = size + (xo2 >> 1);
+    const unsigned nb1 = (x1 + (s1 == 0 ? dnb[0] : s1 == 1 ? dnb[1] : s1 == 2 ? dnb[2] : dnb[3])) >> 16;
+    const unsigned nb2 = (x2 + (s2 == 0 ? dnb[0] : s2 == 1 ? dnb[1] : s2 == 2 ? dnb[2] : dnb[3])) >> 16;
+    o[j >> 1] = ((nb1 << 12) | (x1 & ((1u << nb1) - 1u))) | (((nb2 << 12) | (x2 & ((1u << nb2) - 1u))) << 16);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
-__global__ void __launch_bounds__(64)
+// TWO = false: one symbol per step.  TWO = true: two symbols per step through
+// T2[s2][s1][x - size] (16 << log u16 entries, 64 KB at log 11), for the few long chains.
+template <bool TWO>
+__global__ void __launch_bounds__(128)
 k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-            const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ rank_of, unsigned n_sym,
+            const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ order, unsigned n_sym,
             const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
             uint16_t *__restrict__ final_state, StreamResult *res) {
   extern __shared__ uint32_t lds[];
-  __shared__ uint4 symbuf[SEQ_CHUNK / 16];
-  __shared__ uint16_t statebuf[SEQ_CHUNK];  // (state - size) * 2 in front of every symbol
+  __shared__ uint4 symbuf[2][SEQ_CHUNK / 16];
+  __shared__ uint16_t statebuf[2][TWO ? SEQ_CHUNK / 2 : SEQ_CHUNK];  // (state - size) * 2
   constexpr unsigned B = SeqModel::B;
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
-  const unsigned c = blockIdx.x, lane = fq_lane();
+  // order[0..B) = contexts by descending chain length, order[B..2B) = rank of every context
+  const unsigned c = TWO ? order[blockIdx.x] : blockIdx.x;
   const unsigned n = ctx_count[c];
   if (n == 0) return;
-  if (rank_of && seq_chain_is_hot(n, rank_of[c], n_sym)) return;  // k_chain_seq2 walks this one
+  if (TWO) { if (!seq_chain_is_hot(n, blockIdx.x, n_sym)) return; }
+  else if (order && seq_chain_is_hot(n, order[B + c], n_sym)) return;  // the two-symbol kernel walks it
+  const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
   const uint32_t *tbl = ct + ct_off[c];
   const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
   const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
   const uint32_t *tt = tbl + 1 + (size >> 1);
   uint16_t *next = reinterpret_cast<uint16_t *>(lds);  // [4][size]
+  uint16_t *t2 = next + 4 * size;                      // [16][size] (TWO only)
   unsigned dnb[4];
 #pragma unroll
   for (int s = 0; s < 4; s++) dnb[s] = tt[2 * s + 1];
-  for (unsigned e = lane; e < 4 * size; e += 64) {
+  for (unsigned e = threadIdx.x; e < 4 * size; e += 128) {
     const unsigned s = e >> log, xi = e & (size - 1), x = size + xi;
     const unsigned nb = (x + tt[2 * s + 1]) >> 16;
     next[e] = (uint16_t)(((unsigned)st[(int)(x >> nb) + (int)tt[2 * s]] - size) * 2u);
   }
+  __syncthreads();
+  const char *nbase = reinterpret_cast<const char *>(next);
+  if (TWO) {
+    for (unsigned e = threadIdx.x; e < 16 * size; e += 128) {
+      const unsigned xi = e & (size - 1), s1 = (e >> log) & 3u, s2 = e >> (log + 2);
+      const unsigned mid = next[(s1 << log) + xi];
+      t2[e] = *reinterpret_cast<const uint16_t *>(nbase + ((s2 << (log + 1)) + mid));
+    }
+  }
+  const char *tbase = reinterpret_cast<const char *>(t2);
   const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + ctx_start[c]);  // 16-byte aligned (CTX_PAD)
   uint4 *gout = reinterpret_cast<uint4 *>(out16 + ctx_start[c]);
-  const char *nbase = reinterpret_cast<const char *>(next);
-  const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf);
-  unsigned xo = 0;  // (state - size) * 2, meaningful in lane 0 only
-  for (unsigned c0 = 0; c0 < n; c0 += SEQ_CHUNK) {
-    const unsigned len = min(SEQ_CHUNK, n - c0);
-    const unsigned q16 = (len + 15) >> 4;  // the run is padded to 16, reading the pad is harmless
-    for (unsigned v = lane; v < q16; v += 64) symbuf[v] = gsym[(c0 >> 4) + v];
-    __syncthreads();
-    if (lane == 0) {
-      const unsigned full = len >> 4;
-      uint4 *state4 = reinterpret_cast<uint4 *>(statebuf);
-      uint4 sv = symbuf[0];
-      for (unsigned g = 0; g < full; g++) {
-        const uint4 sv_next = symbuf[g + 1 < q16 ? g + 1 : g];  // lands while this group is walked
-        const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
-        unsigned xs[16];
+  const unsigned n_chunks = (n + SEQ_CHUNK - 1) / SEQ_CHUNK;
+  // prologue: chunk 0 staged by wave 1
+  if (wave == 1) {
+    const unsigned q16 = (min(SEQ_CHUNK, n) + 15) >> 4;  // the run is padded to 16: reading the pad is harmless
+    for (unsigned v = lane; v < q16; v += 64) symbuf[0][v] = gsym[v];
+  }
+  __syncthreads();
+  unsigned xo = 0;  // (state - size) * 2, meaningful in wave 0 lane 0 only
+  for (unsigned k = 0; k <= n_chunks; k++) {
+    if (wave == 0) {
+      if (lane == 0 && k < n_chunks) {
+        const unsigned len = min(SEQ_CHUNK, n - k * SEQ_CHUNK);
+        const unsigned q16 = (len + 15) >> 4, full = len >> 4;
+        const uint4 *sb = symbuf[k & 1];
+        const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(sb);
+        uint16_t *stb = statebuf[k & 1];
+        uint4 *state4 = reinterpret_cast<uint4 *>(stb);
+        uint4 sv = sb[0];
+        for (unsigned g = 0; g < full; g++) {
+          const uint4 sv_next = sb[g + 1 < q16 ? g + 1 : g];  // lands while this group is walked
+          const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
+          if (TWO) {
+            unsigned xs[8];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-          const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & 3u;
-          xs[j] = xo;
+            for (int j = 0; j < 8; j++) {  // pair j = symbols 2j, 2j+1 of the group
+              const unsigned half = w[j >> 1] >> (16 * (j & 1));
+              const unsigned pc = (half & 3u) | ((half >> 6) & 0xCu);  // s1 | s2 << 2
+              xs[j] = xo;
+              xo = *reinterpret_cast<const uint16_t *>(tbase + ((pc << (log + 1)) + xo));
+            }
+            state4[g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
+          } else {
+            unsigned xs[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+              const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & 3u;
+              xs[j] = xo;
+              xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+            }
+            state4[2 * g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
+            state4[2 * g + 1] = make_uint4(xs[8] | (xs[9] << 16), xs[10] | (xs[11] << 16), xs[12] | (xs[13] << 16), xs[14] | (xs[15] << 16));
+          }
+          sv = sv_next;
+        }
+        // ragged end of the last chunk, one symbol at a time (TWO: the partner state of an even
+        // symbol is recomputed by the output pass, so only even positions are recorded)
+        for (unsigned i = full << 4; i < len; i++) {
+          const unsigned s = sbytes[i] & 3u;
+          if (!TWO) stb[i] = (uint16_t)xo;
+          else if (!(i & 1u)) stb[i >> 1] = (uint16_t)xo;
           xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
         }
-        // 16 states leave as two 16-byte LDS writes instead of sixteen 2-byte ones
-        state4[2 * g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
-        state4[2 * g + 1] = make_uint4(xs[8] | (xs[9] << 16), xs[10] | (xs[11] << 16), xs[12] | (xs[13] << 16), xs[14] | (xs[15] << 16));
-        sv = sv_next;
       }
-      for (unsigned i = full << 4; i < len; i++) {
-        const unsigned s = sbytes[i] & 3u;
-        statebuf[i] = (uint16_t)xo;
-        xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+    } else {
+      if (k >= 1) {  // outputs of chunk k-1
+        const unsigned kk = k - 1;
+        const unsigned len = min(SEQ_CHUNK, n - kk * SEQ_CHUNK);
+        const unsigned q8 = (len + 7) >> 3;
+        const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf[kk & 1]);
+        for (unsigned v = lane; v < q8; v += 64)
+          gout[kk * (SEQ_CHUNK / 8) + v] = seq_outputs8<TWO ? 2 : 1>(sbytes, statebuf[kk & 1], nbase, v, log, size, dnb);
       }
-    }
-    __syncthreads();
-    // (state, symbol) -> (nb << 12 | low nb bits of the state): FSE_encodeSymbol's emission
-    const unsigned q8 = (len + 7) >> 3;
-    for (unsigned v = lane; v < q8; v += 64) {
-      unsigned o[4];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const unsigned i = v * 8 + j;
-        const unsigned s = sbytes[i] & 3u;
-        const unsigned x = size + ((unsigned)statebuf[i] >> 1);
-        const unsigned nb = (x + (s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3])) >> 16;
-        const unsigned val = (nb << 12) | (x & ((1u << nb) - 1u));
-        if (j & 1) o[j >> 1] |= val << 16; else o[j >> 1] = val;
+      if (k + 1 < n_chunks) {  // stage chunk k+1 (into the buffer whose outputs were just produced)
+        const unsigned kn = k + 1;
+        const unsigned q16 = (min(SEQ_CHUNK, n - kn * SEQ_CHUNK) + 15) >> 4;
+        for (unsigned v = lane; v < q16; v += 64) symbuf[kn & 1][v] = gsym[kn * (SEQ_CHUNK / 16) + v];
       }
-      gout[(c0 >> 3) + v] = make_uint4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
   }
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     final_state[c] = (uint16_t)(size + (xo >> 1));
     atomicMax(&res->refixed, n);
   }
 }
 
-// Two symbols per step: T2[s2][s1][x - size] = state after s1 then s2 (16 << log u16 entries,
-// 64 KB at log 11, two workgroups per CU).  Halves the number of dependent LDS reads of a
-// chain; the state between the two symbols is only needed for the emission of the second one
-// and is recomputed off the critical path (by all lanes, from the L1-resident CTable).
-// Workgroups are dispatched longest chain first (order[]), so the longest chain of the block
-// (context 0xD7 also receives the first base of every read) starts immediately.
+// longest chains first (context 0xD7 also receives the first base of every read): order[0..B)
+// = contexts by descending length, order[B..2B) = rank of every context
 __global__ void __launch_bounds__(256)
 k_seq_order(const uint32_t *__restrict__ arrays, uint32_t *__restrict__ order) {
   __shared__ uint32_t cnt[SeqModel::B];
@@ -547,104 +603,7 @@ k_seq_order(const uint32_t *__restrict__ arrays, uint32_t *__restrict__ order) {
   unsigned rank = 0;
   for (unsigned o = 0; o < (unsigned)SeqModel::B; o++) rank += (cnt[o] > mine) || (cnt[o] == mine && o < c);
   order[rank] = c;
-  order[SeqModel::B + c] = rank;  // rank_of
-}
-
-__global__ void __launch_bounds__(64)
-k_chain_seq2(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-             const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ order, unsigned n_sym,
-             const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
-             uint16_t *__restrict__ final_state, StreamResult *res) {
-  extern __shared__ uint32_t lds[];
-  __shared__ uint4 symbuf[SEQ_CHUNK / 16];
-  __shared__ uint16_t statebuf[SEQ_CHUNK / 2];  // (state - size) * 2 in front of every EVEN symbol
-  constexpr unsigned B = SeqModel::B;
-  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
-  const unsigned c = order[blockIdx.x], lane = fq_lane();
-  const unsigned n = ctx_count[c];
-  if (n == 0 || !seq_chain_is_hot(n, blockIdx.x, n_sym)) return;
-  const uint32_t *tbl = ct + ct_off[c];
-  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
-  const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
-  const uint32_t *tt = tbl + 1 + (size >> 1);
-  unsigned dnb[4];
-  int dfs[4];
-#pragma unroll
-  for (int s = 0; s < 4; s++) { dfs[s] = (int)tt[2 * s]; dnb[s] = tt[2 * s + 1]; }
-  // one FSE_encodeSymbol transition on (state - size), straight from the CTable
-  auto step1 = [&](unsigned s, unsigned xi) -> unsigned {
-    const unsigned x = size + xi;
-    const unsigned d = s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3];
-    const int f = s == 0 ? dfs[0] : s == 1 ? dfs[1] : s == 2 ? dfs[2] : dfs[3];
-    const unsigned nb = (x + d) >> 16;
-    return (unsigned)st[(int)(x >> nb) + f] - size;
-  };
-  uint16_t *t2 = reinterpret_cast<uint16_t *>(lds);  // [s2][s1][size], byte offsets of the next lookup
-  for (unsigned e = lane; e < 16 * size; e += 64) {
-    const unsigned xi = e & (size - 1), s1 = (e >> log) & 3u, s2 = e >> (log + 2);
-    t2[e] = (uint16_t)(step1(s2, step1(s1, xi)) * 2u);
-  }
-  const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + ctx_start[c]);  // 16-byte aligned (CTX_PAD)
-  uint4 *gout = reinterpret_cast<uint4 *>(out16 + ctx_start[c]);
-  const char *tbase = reinterpret_cast<const char *>(t2);
-  const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf);
-  unsigned xo = 0;  // (state - size) * 2, meaningful in lane 0 only
-  for (unsigned c0 = 0; c0 < n; c0 += SEQ_CHUNK) {
-    const unsigned len = min(SEQ_CHUNK, n - c0);
-    const unsigned q16 = (len + 15) >> 4;
-    for (unsigned v = lane; v < q16; v += 64) symbuf[v] = gsym[(c0 >> 4) + v];
-    __syncthreads();
-    if (lane == 0) {
-      const unsigned full = len >> 4;
-      uint4 *state4 = reinterpret_cast<uint4 *>(statebuf);
-      uint4 sv = symbuf[0];
-      for (unsigned g = 0; g < full; g++) {
-        const uint4 sv_next = symbuf[g + 1 < q16 ? g + 1 : g];  // lands while this group is walked
-        const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
-        unsigned xs[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {  // pair j = symbols 2j, 2j+1 of the group
-          const unsigned half = w[j >> 1] >> (16 * (j & 1));
-          const unsigned pc = (half & 3u) | ((half >> 6) & 0xCu);  // s1 | s2 << 2
-          xs[j] = xo;
-          xo = *reinterpret_cast<const uint16_t *>(tbase + ((pc << (log + 1)) + xo));
-        }
-        state4[g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
-        sv = sv_next;
-      }
-      for (unsigned i = full << 4; i + 1 < len; i += 2) {
-        const unsigned pc = (sbytes[i] & 3u) | ((sbytes[i + 1] & 3u) << 2);
-        statebuf[i >> 1] = (uint16_t)xo;
-        xo = *reinterpret_cast<const uint16_t *>(tbase + ((pc << (log + 1)) + xo));
-      }
-      if (len & 1u) {  // only the last chunk of a chain can be odd
-        statebuf[len >> 1] = (uint16_t)xo;
-        xo = step1(sbytes[len - 1] & 3u, xo >> 1) * 2u;
-      }
-    }
-    __syncthreads();
-    const unsigned q8 = (len + 7) >> 3;
-    for (unsigned v = lane; v < q8; v += 64) {
-      unsigned o[4];
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        const unsigned i = v * 8 + j;
-        const unsigned s1 = sbytes[i] & 3u, s2 = sbytes[i + 1] & 3u;
-        const unsigned xi1 = (unsigned)statebuf[i >> 1] >> 1;
-        const unsigned xi2 = step1(s1, xi1);  // state between the two symbols
-        const unsigned x1 = size + xi1, x2 = size + xi2;
-        const unsigned nb1 = (x1 + (s1 == 0 ? dnb[0] : s1 == 1 ? dnb[1] : s1 == 2 ? dnb[2] : dnb[3])) >> 16;
-        const unsigned nb2 = (x2 + (s2 == 0 ? dnb[0] : s2 == 1 ? dnb[1] : s2 == 2 ? dnb[2] : dnb[3])) >> 16;
-        o[j >> 1] = ((nb1 << 12) | (x1 & ((1u << nb1) - 1u))) | (((nb2 << 12) | (x2 & ((1u << nb2) - 1u))) << 16);
-      }
-      gout[(c0 >> 3) + v] = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-    __syncthreads();
-  }
-  if (lane == 0) {
-    final_state[c] = (uint16_t)(size + (xo >> 1));
-    atomicMax(&res->refixed, n);
-  }
+  order[SeqModel::B + c] = rank;
 }
 
 // ------------------------------------------------------------------ K6: bit offsets and packing
@@ -846,31 +805,33 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
-  if (serial_seq && tab.max_log <= 11 && ctx->seq_all_t2) {
+  if (serial_seq) {
     uint32_t *order = reinterpret_cast<uint32_t *>(final_state + B);
+    const unsigned lds1 = 8u << tab.max_log, lds2 = 40u << tab.max_log;
+    const bool can_two = tab.max_log <= 11 && !ctx->seq_one_symbol;
     hipLaunchKernelGGL(k_seq_order, dim3(1), dim3(256), 0, st, arrays, order);
-    hipLaunchKernelGGL(k_chain_seq2, dim3(B), dim3(64), 32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
-                       sc.out16.as<uint16_t>(), arrays, order, 0u, tab.ct, tab.ct_off, final_state, res);
-  } else if (serial_seq && tab.max_log <= 11 && !ctx->seq_one_symbol) {
-    // the few long chains: two symbols per step (64 KB table each) on the lane's third stream,
-    // everything else: one symbol per step (16 KB table) here -- both kernels run side by side
-    uint32_t *order = reinterpret_cast<uint32_t *>(final_state + B);
-    hipLaunchKernelGGL(k_seq_order, dim3(1), dim3(256), 0, st, arrays, order);
-    FQ_HIP(hipEventRecord(lane.ev_scat, st));
-    FQ_HIP(hipStreamWaitEvent(lane.st_hot, lane.ev_scat, 0));
-    fq_timer_span_begin(ctx, "seq.chains.hot", lane.st_hot);
-    hipLaunchKernelGGL(k_chain_seq2, dim3(SEQ_HOT_MAX), dim3(64), 32u << tab.max_log, lane.st_hot,
-                       sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, order, n_sym, tab.ct,
-                       tab.ct_off, final_state, res);
-    fq_timer_span_end(ctx, lane.st_hot);
-    FQ_HIP(hipEventRecord(lane.ev_hot, lane.st_hot));
-    hipLaunchKernelGGL(k_chain_seq, dim3(B), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
-                       sc.out16.as<uint16_t>(), arrays, order + B, n_sym, tab.ct, tab.ct_off, final_state, res);
-    FQ_HIP(hipStreamWaitEvent(st, lane.ev_hot, 0));
-  } else if (serial_seq) {
-    hipLaunchKernelGGL(k_chain_seq, dim3(B), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
-                       sc.out16.as<uint16_t>(), arrays, (const uint32_t *)nullptr, n_sym, tab.ct, tab.ct_off,
-                       final_state, res);
+    if (can_two && ctx->seq_all_t2) {
+      hipLaunchKernelGGL(k_chain_seq<true>, dim3(B), dim3(128), lds2, st, sc.sorted_sym.as<uint8_t>(),
+                         sc.out16.as<uint16_t>(), arrays, order, 0u, tab.ct, tab.ct_off, final_state, res);
+    } else if (can_two) {
+      // the few long chains: two symbols per step (64 KB table each) on the lane's third stream,
+      // everything else: one symbol per step (16 KB table) here -- both kernels run side by side
+      FQ_HIP(hipEventRecord(lane.ev_scat, st));
+      FQ_HIP(hipStreamWaitEvent(lane.st_hot, lane.ev_scat, 0));
+      fq_timer_span_begin(ctx, "seq.chains.hot", lane.st_hot);
+      hipLaunchKernelGGL(k_chain_seq<true>, dim3(SEQ_HOT_MAX), dim3(128), lds2, lane.st_hot,
+                         sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, order, n_sym, tab.ct,
+                         tab.ct_off, final_state, res);
+      fq_timer_span_end(ctx, lane.st_hot);
+      FQ_HIP(hipEventRecord(lane.ev_hot, lane.st_hot));
+      hipLaunchKernelGGL(k_chain_seq<false>, dim3(B), dim3(128), lds1, st, sc.sorted_sym.as<uint8_t>(),
+                         sc.out16.as<uint16_t>(), arrays, order, n_sym, tab.ct, tab.ct_off, final_state, res);
+      FQ_HIP(hipStreamWaitEvent(st, lane.ev_hot, 0));
+    } else {
+      hipLaunchKernelGGL(k_chain_seq<false>, dim3(B), dim3(128), lds1, st, sc.sorted_sym.as<uint8_t>(),
+                         sc.out16.as<uint16_t>(), arrays, (const uint32_t *)nullptr, n_sym, tab.ct, tab.ct_off,
+                         final_state, res);
+    }
   } else {
     hipLaunchKernelGGL(k_chains_reset<M>, dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                        sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, res);
