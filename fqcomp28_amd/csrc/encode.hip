@@ -28,6 +28,8 @@
 //   K7 epilogue              : state flush + end mark + size/overflow
 #include "fqgpu_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr unsigned TILE_SEQ = 32768;   // symbols per partition tile (one wave each in K3)
@@ -788,7 +790,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   (void)pfx;
 
   FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");
-  hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(M::STREAM ? 1024 : 256), 0, st, b->raw, b->recs,
+  static const unsigned hist_threads_q = getenv("FQGPU_HIST_THREADS") ? (unsigned)atoi(getenv("FQGPU_HIST_THREADS")) : 1024u;
+  hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(M::STREAM ? hist_threads_q : 256), 0, st, b->raw, b->recs,
                      rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), sc.keys.as<uint32_t>(), res);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");
