@@ -482,6 +482,9 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
   extern __shared__ uint32_t lds[];
   __shared__ uint4 symbuf[2][SEQ_CHUNK / 16];
   __shared__ uint16_t statebuf[2][TWO ? SEQ_CHUNK / 2 : SEQ_CHUNK];  // (state - size) * 2
+  // byte offset of the table row every step reads: (symbol or symbol pair) << (log + 1),
+  // prepared by the helper wave so the walker's step is add + LDS read and nothing else
+  __shared__ uint16_t offbuf[2][TWO ? SEQ_CHUNK / 2 : SEQ_CHUNK];
   constexpr unsigned B = SeqModel::B;
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
   // order[0..B) = contexts by descending chain length, order[B..2B) = rank of every context
@@ -518,11 +521,34 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
   const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + ctx_start[c]);  // 16-byte aligned (CTX_PAD)
   uint4 *gout = reinterpret_cast<uint4 *>(out16 + ctx_start[c]);
   const unsigned n_chunks = (n + SEQ_CHUNK - 1) / SEQ_CHUNK;
-  // prologue: chunk 0 staged by wave 1
-  if (wave == 1) {
-    const unsigned q16 = (min(SEQ_CHUNK, n) + 15) >> 4;  // the run is padded to 16: reading the pad is harmless
-    for (unsigned v = lane; v < q16; v += 64) symbuf[0][v] = gsym[v];
-  }
+  // symbols of chunk kn -> symbuf + row offsets (the run is padded to 16: reading the pad is harmless)
+  auto stage = [&](unsigned kn) {
+    const unsigned q16 = (min(SEQ_CHUNK, n - kn * SEQ_CHUNK) + 15) >> 4;
+    for (unsigned v = lane; v < q16; v += 64) {
+      const uint4 sv = gsym[kn * (SEQ_CHUNK / 16) + v];
+      symbuf[kn & 1][v] = sv;
+      const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
+      unsigned o[8];
+      if (TWO) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const unsigned word = w[j >> 1];  // four symbols = two pairs
+          const unsigned pc0 = (word & 3u) | ((word >> 6) & 0xCu), pc1 = ((word >> 16) & 3u) | ((word >> 22) & 0xCu);
+          o[j >> 1] = (pc0 << (log + 1)) | ((pc1 << (log + 1)) << 16);
+        }
+        reinterpret_cast<uint4 *>(offbuf[kn & 1])[v] = make_uint4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          const unsigned s0 = (w[j >> 2] >> (8 * (j & 3))) & 3u, s1 = (w[j >> 2] >> (8 * ((j + 1) & 3))) & 3u;
+          o[j >> 1] = (s0 << (log + 1)) | ((s1 << (log + 1)) << 16);
+        }
+        reinterpret_cast<uint4 *>(offbuf[kn & 1])[2 * v] = make_uint4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<uint4 *>(offbuf[kn & 1])[2 * v + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  };
+  if (wave == 1) stage(0);  // prologue
   __syncthreads();
   unsigned xo = 0;  // (state - size) * 2, meaningful in wave 0 lane 0 only
   for (unsigned k = 0; k <= n_chunks; k++) {
@@ -530,36 +556,40 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
       if (lane == 0 && k < n_chunks) {
         const unsigned len = min(SEQ_CHUNK, n - k * SEQ_CHUNK);
         const unsigned q16 = (len + 15) >> 4, full = len >> 4;
-        const uint4 *sb = symbuf[k & 1];
-        const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(sb);
+        const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf[k & 1]);
         uint16_t *stb = statebuf[k & 1];
         uint4 *state4 = reinterpret_cast<uint4 *>(stb);
-        uint4 sv = sb[0];
-        for (unsigned g = 0; g < full; g++) {
-          const uint4 sv_next = sb[g + 1 < q16 ? g + 1 : g];  // lands while this group is walked
-          const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
-          if (TWO) {
+        const uint4 *off4 = reinterpret_cast<const uint4 *>(offbuf[k & 1]);
+        if (TWO) {
+          uint4 ov = off4[0];
+          for (unsigned g = 0; g < full; g++) {  // 16 symbols = 8 pair steps
+            const uint4 ov_next = off4[g + 1 < q16 ? g + 1 : g];  // lands while this group is walked
+            const unsigned w[4] = {ov.x, ov.y, ov.z, ov.w};
             unsigned xs[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {  // pair j = symbols 2j, 2j+1 of the group
-              const unsigned half = w[j >> 1] >> (16 * (j & 1));
-              const unsigned pc = (half & 3u) | ((half >> 6) & 0xCu);  // s1 | s2 << 2
+            for (int j = 0; j < 8; j++) {
               xs[j] = xo;
-              xo = *reinterpret_cast<const uint16_t *>(tbase + ((pc << (log + 1)) + xo));
+              xo = *reinterpret_cast<const uint16_t *>(tbase + (((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + xo));
             }
             state4[g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
-          } else {
+            ov = ov_next;
+          }
+        } else {
+          uint4 ov0 = off4[0], ov1 = off4[1];
+          for (unsigned g = 0; g < full; g++) {  // 16 one-symbol steps
+            const unsigned gn = g + 1 < q16 ? g + 1 : g;
+            const uint4 n0 = off4[2 * gn], n1 = off4[2 * gn + 1];
+            const unsigned w[8] = {ov0.x, ov0.y, ov0.z, ov0.w, ov1.x, ov1.y, ov1.z, ov1.w};
             unsigned xs[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-              const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & 3u;
               xs[j] = xo;
-              xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+              xo = *reinterpret_cast<const uint16_t *>(nbase + (((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + xo));
             }
             state4[2 * g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
             state4[2 * g + 1] = make_uint4(xs[8] | (xs[9] << 16), xs[10] | (xs[11] << 16), xs[12] | (xs[13] << 16), xs[14] | (xs[15] << 16));
+            ov0 = n0; ov1 = n1;
           }
-          sv = sv_next;
         }
         // ragged end of the last chunk, one symbol at a time (TWO: the partner state of an even
         // symbol is recomputed by the output pass, so only even positions are recorded)
@@ -579,11 +609,7 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
         for (unsigned v = lane; v < q8; v += 64)
           gout[kk * (SEQ_CHUNK / 8) + v] = seq_outputs8<TWO ? 2 : 1>(sbytes, statebuf[kk & 1], nbase, v, log, size, dnb);
       }
-      if (k + 1 < n_chunks) {  // stage chunk k+1 (into the buffer whose outputs were just produced)
-        const unsigned kn = k + 1;
-        const unsigned q16 = (min(SEQ_CHUNK, n - kn * SEQ_CHUNK) + 15) >> 4;
-        for (unsigned v = lane; v < q16; v += 64) symbuf[kn & 1][v] = gsym[kn * (SEQ_CHUNK / 16) + v];
-      }
+      if (k + 1 < n_chunks) stage(k + 1);  // into the buffers whose outputs were just produced
     }
     __syncthreads();
   }
