@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--decode-block-mib", type=int, default=1, help="block size of the many-blocks decode run")
     ap.add_argument("--decode-mib", type=int, default=256, help="data decoded in the many-blocks run")
     ap.add_argument("--lanes", type=int, default=4, help="blocks in flight per GPU (encode lanes)")
-    ap.add_argument("--seq-mode", default="split", choices=["split", "all2", "one", "generic"],
+    ap.add_argument("--seq-mode", default="all2", choices=["split", "all2", "one", "generic"],
                     help="sequence chain kernels: long chains two symbols/step (default), all two, all one, reset-cut")
     ap.add_argument("--skip-decode", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")

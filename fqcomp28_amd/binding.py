@@ -255,8 +255,8 @@ class Context:
 
     __del__ = close
 
-    def set_chain_params(self, segment=0, seq_generic=False, seq_one_symbol=False, seq_all_t2=False):
-        flags = (1 if seq_generic else 0) | (2 if seq_one_symbol else 0) | (4 if seq_all_t2 else 0)
+    def set_chain_params(self, segment=0, seq_generic=False, seq_one_symbol=False, seq_all_t2=True):
+        flags = (1 if seq_generic else 0) | (2 if seq_one_symbol else 0) | (0 if seq_all_t2 else 4)
         _check(lib().fqgpu_ctx_set_chain_params(self.h, segment, flags), "set_chain_params")
 
     def set_lanes(self, lanes):

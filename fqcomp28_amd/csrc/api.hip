@@ -372,7 +372,7 @@ extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsi
   }
   ctx->seq_generic = (flags & FQGPU_CHAIN_SEQ_GENERIC) ? 1 : 0;
   ctx->seq_one_symbol = (flags & FQGPU_CHAIN_SEQ_ONE_SYMBOL) ? 1 : 0;
-  ctx->seq_all_t2 = (flags & FQGPU_CHAIN_SEQ_ALL_TWO_SYMBOL) ? 1 : 0;
+  ctx->seq_all_t2 = (flags & FQGPU_CHAIN_SEQ_LONG_TWO_SYMBOL) ? 0 : 1;
   return FQGPU_OK;
 }
 

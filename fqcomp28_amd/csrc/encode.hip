@@ -551,6 +551,9 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
   if (wave == 1) stage(0);  // prologue
   __syncthreads();
   unsigned xo = 0;  // (state - size) * 2, meaningful in wave 0 lane 0 only
+  // the walker is the critical path of the whole block: it wins issue arbitration against
+  // whatever else shares its SIMD
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);
   for (unsigned k = 0; k <= n_chunks; k++) {
     if (wave == 0) {
       if (lane == 0 && k < n_chunks) {

@@ -125,7 +125,7 @@ struct fqgpu_ctx {
   unsigned seg_len = 1024;       // nominal segment of the reset-cut chain kernel
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
   int seq_one_symbol = 0;        // 1: serial sequence kernel with one symbol per step (no T2 table)
-  int seq_all_t2 = 0;            // 1: every sequence chain takes the two-symbol kernel
+  int seq_all_t2 = 1;            // 1: every sequence chain takes the two-symbol kernel (default); 0: only the long ones
   unsigned n_lanes = 4, next_lane = 0;
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch

@@ -87,11 +87,11 @@ void fqgpu_ctx_destroy(fqgpu_ctx *ctx);
  * segment: nominal length, in symbols, of the pieces a context's chain is cut into at
  * single-state ("reset") symbols (0 keeps the default).  flags: FQGPU_CHAIN_SEQ_GENERIC
  * runs the sequence stream through the same reset-cut kernel instead of the serial
- * one-lane-per-context kernels (two symbols per step by default, one with
- * FQGPU_CHAIN_SEQ_ONE_SYMBOL or when a table log exceeds 11). */
+ * one-lane-per-context kernels (two symbols per step through a 64 KB LDS table by default;
+ * one symbol per step with FQGPU_CHAIN_SEQ_ONE_SYMBOL or when a table log exceeds 11). */
 #define FQGPU_CHAIN_SEQ_GENERIC 1u
 #define FQGPU_CHAIN_SEQ_ONE_SYMBOL 2u /* serial sequence kernel without the two-symbol table */
-#define FQGPU_CHAIN_SEQ_ALL_TWO_SYMBOL 4u /* two-symbol table for every sequence chain, not only the long ones */
+#define FQGPU_CHAIN_SEQ_LONG_TWO_SYMBOL 4u /* two-symbol table only for the few long chains (third stream), one-symbol for the rest */
 int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned flags);
 /* Number of blocks the handle keeps in flight (encode lanes, 1..8, default 4): each
  * fqgpu_dblock_encode goes to the next lane (own HIP streams and scratch). */

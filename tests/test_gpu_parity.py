@@ -133,13 +133,13 @@ def test_tables_from_counts_normalisation_corner_cases(F):
 
 # ---------------------------------------------------------------- how the chains are cut never shows in the output
 @pytest.mark.parametrize("seg,seq_generic,lanes", [(2, True, 1), (16, True, 3), (64, False, 2), (100000, True, 1),
-                                                   (1024, False, 4), (1024, "one", 2)])
+                                                   (1024, False, 4), (1024, "one", 2), (1024, "split", 2)])
 def test_chain_parameters_never_change_the_bits(F, golden_dir, seg, seq_generic, lanes):
     raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_2.fastq"))
     _, _, sft, qft = O.freq_tables(raw, recs)
     e = O.OracleCtx(sft, qft).encode(raw, recs)
     ctx = F.Context(sft, qft)
-    ctx.set_chain_params(seg, seq_generic is True, seq_generic == "one")
+    ctx.set_chain_params(seg, seq_generic is True, seq_generic == "one", seq_all_t2=seq_generic != "split")
     ctx.set_lanes(lanes)
     blocks = [ctx.dblock(raw, recs) for _ in range(3)]  # several blocks in flight on the lanes
     for b in blocks:
