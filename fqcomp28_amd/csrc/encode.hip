@@ -153,19 +153,31 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   bool bad = false;
   if (wb < we) {
     SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb)};
+    // two-stage pipeline: the bytes of chunk i+1 are in flight while chunk i is hashed and stored
+    fqgpu_rec rec;
+    unsigned p;
+    w.locate(wb, we, wb + lane, wb + lane < we, rec, p);
+    SymBytes cur = fq_load_sym_bytes<M>(raw, rec, p, wb + lane < we);
+    unsigned cur_p = p;
     for (unsigned eb = wb; eb < we; eb += 64) {
       const unsigned e = eb + lane;
       const bool valid = e < we;
-      fqgpu_rec rec;
-      unsigned p;
-      w.locate(eb, we, e, valid, rec, p);
+      SymBytes nxt = cur;
+      unsigned nxt_p = 0;
+      if (eb + 64 < we) {
+        const bool nvalid = e + 64 < we;
+        w.locate(eb + 64, we, e + 64, nvalid, rec, nxt_p);
+        nxt = fq_load_sym_bytes<M>(raw, rec, nxt_p, nvalid);
+      }
       if (valid) {
         unsigned ctx, sym;
-        fq_sym_ctx<M>(raw, rec, p, ctx, sym);
+        fq_ctx_from_bytes<M>(cur, cur_p, ctx, sym);
         bad |= sym >= (unsigned)M::A;
         keys[e] = ctx | ((sym & (unsigned)(M::A - 1)) << 16);
         atomicAdd(&hist[ctx], 1u);
       }
+      cur = nxt;
+      cur_p = nxt_p;
     }
   }
   if (bad) atomicOr(&res->bad_symbol, 1u);

@@ -227,38 +227,53 @@ __device__ __forceinline__ unsigned fq_locate(const uint32_t *__restrict__ rec_s
   return lo;
 }
 
-// (context, symbol) of position p of a record; encode-side definition
-// (SequenceEncoder::encodeRecord src/fse_sequence.cpp:53-112: context = the four
-// bases in front of p, nearest in bits 7:6, virtual T,C,C,T = 0xD7 before the read)
-__device__ __forceinline__ void fq_seq_sym_ctx(const uint8_t *__restrict__ s, unsigned p,
-                                               unsigned &ctx, unsigned &sym) {
-  sym = fq_base_code(s[p]);
-  unsigned c = 0;
+// ---- (context, symbol) of position p of a record, encode-side definition, in two halves so
+// that callers can issue the loads of the NEXT chunk before they consume (and store results
+// of) the current one: vmcnt retires in order, a store between two loads would serialise them.
+//   sequence (SequenceEncoder::encodeRecord src/fse_sequence.cpp:53-112): context = the four
+//     bases in front of p, nearest in bits 7:6, virtual T,C,C,T = 0xD7 before the read
+//   quality (QualityEncoder::encodeRecord src/fse_quality.cpp:5-53, L >= 3): context of p is
+//     calcContext(Q[p-1], Q[p-2], Q[p-3]) with zeros in front of the read
+struct SymBytes {
+  unsigned b[5];  // byte at p, p-1, ..., p-4 (0 where the position is in front of the read)
+};
+
+template <class M>
+__device__ __forceinline__ SymBytes fq_load_sym_bytes(const uint8_t *__restrict__ raw, const fqgpu_rec &rec,
+                                                      unsigned p, bool valid) {
+  SymBytes r;
+  const uint8_t *s = raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off);
+  constexpr int N = M::STREAM == 0 ? 5 : 4;
 #pragma unroll
-  for (int k = 1; k <= 4; k++) {
-    const int q = (int)p - k;
-    const unsigned code = q >= 0 ? fq_base_code(s[q]) : ((0xD7u >> (2 * (4 + q))) & 3u);
-    c |= code << (2 * (4 - k));
-  }
-  ctx = c;
+  for (int k = 0; k < 5; k++) r.b[k] = (k < N && valid && p >= (unsigned)k) ? (unsigned)s[p - k] : 0u;
+  return r;
 }
 
-// QualityEncoder::encodeRecord src/fse_quality.cpp:5-53 (L >= 3): context of p is
-// calcContext(Q[p-1], Q[p-2], Q[p-3]) with zeros in front of the read
-__device__ __forceinline__ void fq_qual_sym_ctx(const uint8_t *__restrict__ qs, unsigned p,
-                                                unsigned &ctx, unsigned &sym) {
-  sym = (unsigned)qs[p] - 33u;
-  const unsigned q = p >= 1 ? (unsigned)qs[p - 1] - 33u : 0u;
-  const unsigned q1 = p >= 2 ? (unsigned)qs[p - 2] - 33u : 0u;
-  const unsigned q2 = p >= 3 ? (unsigned)qs[p - 3] - 33u : 0u;
-  ctx = fq_qual_ctx(q & 63u, q1 & 63u, q2 & 63u);
+template <class M>
+__device__ __forceinline__ void fq_ctx_from_bytes(const SymBytes &r, unsigned p, unsigned &ctx, unsigned &sym) {
+  if (M::STREAM == 0) {
+    sym = fq_base_code(r.b[0]);
+    unsigned c = 0;
+#pragma unroll
+    for (int k = 1; k <= 4; k++) {
+      const unsigned code = p >= (unsigned)k ? fq_base_code(r.b[k]) : ((0xD7u >> (2 * (4 + (int)p - k))) & 3u);
+      c |= code << (2 * (4 - k));
+    }
+    ctx = c;
+  } else {
+    sym = r.b[0] - 33u;
+    const unsigned q = p >= 1 ? r.b[1] - 33u : 0u;
+    const unsigned q1 = p >= 2 ? r.b[2] - 33u : 0u;
+    const unsigned q2 = p >= 3 ? r.b[3] - 33u : 0u;
+    ctx = fq_qual_ctx(q & 63u, q1 & 63u, q2 & 63u);
+  }
 }
 
 template <class M>
 __device__ __forceinline__ void fq_sym_ctx(const uint8_t *__restrict__ raw, const fqgpu_rec &rec,
                                            unsigned p, unsigned &ctx, unsigned &sym) {
-  if (M::STREAM == 0) fq_seq_sym_ctx(raw + rec.seq_off, p, ctx, sym);
-  else fq_qual_sym_ctx(raw + rec.qual_off, p, ctx, sym);
+  const SymBytes r = fq_load_sym_bytes<M>(raw, rec, p, true);
+  fq_ctx_from_bytes<M>(r, p, ctx, sym);
 }
 
 #endif  // __HIPCC__
