@@ -305,6 +305,68 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
   }
 }
 
+// Sequence variant of K3 with the tile's partition staged in LDS: the symbols of a tile are
+// grouped by context inside a 32 KB LDS buffer and every context's run leaves as one
+// contiguous copy (128 B on average) instead of 128 byte stores scattered over the walk --
+// the byte-granular scatter of k_scatter completes partial lines in HBM (measured 3.7 GB
+// written for 0.6 GB of payload per 256 MiB block).
+__global__ void __launch_bounds__(64)
+k_scatter_seq_staged(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
+                     const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ tile_base,
+                     uint8_t *__restrict__ sorted_sym, uint32_t *__restrict__ slot_of) {
+  constexpr unsigned B = SeqModel::B;
+  __shared__ uint8_t stage[TILE_SEQ];
+  __shared__ uint32_t lcur[B], lstart[B + 1], gbase[B];
+  const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x;
+  const unsigned e0 = tile * T;
+  const unsigned e1 = min(e0 + T, n_sym);
+  // local layout: exclusive scan of this tile's histogram (4 contexts per lane)
+  unsigned cnt[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { cnt[k] = tile_hist[(size_t)tile * B + lane * 4 + k]; sum += cnt[k]; }
+  unsigned inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(inc, d);
+    if (lane >= (unsigned)d) inc += o;
+  }
+  unsigned run = inc - sum;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned c = lane * 4 + k;
+    lstart[c] = run; lcur[c] = run;
+    gbase[c] = tile_base[(size_t)tile * B + c];
+    run += cnt[k];
+  }
+  if (lane == 63) lstart[B] = run;
+  unsigned key_next = e0 + lane < e1 ? keys[e0 + lane] : 0u;
+  __syncthreads();
+  for (unsigned eb = e0; eb < e1; eb += 64) {
+    const unsigned e = eb + lane;
+    const bool valid = e < e1;
+    const unsigned key = key_next;
+    key_next = e + 64 < e1 ? keys[e + 64] : 0u;  // in flight while this chunk is ranked
+    const unsigned ctx = key & 0xFFu;
+    const unsigned long long grp = fq_match_any<SeqModel::KEYBITS>(ctx, valid);
+    const unsigned rank = fq_mbcnt(grp);
+    const unsigned cur = lcur[ctx];
+    __syncthreads();  // every lane has read its cursor before any leader advances it
+    if (valid) {
+      if (rank == 0) lcur[ctx] = cur + (unsigned)__popcll(grp);
+      const unsigned p = cur + rank;
+      stage[p] = (uint8_t)(key >> 16);
+      slot_of[e] = gbase[ctx] + (p - lstart[ctx]);
+    }
+    __syncthreads();
+  }
+  // every context's run leaves as one contiguous copy
+  for (unsigned c = 0; c < B; c++) {
+    const unsigned b = lstart[c], len = lstart[c + 1] - b;
+    uint8_t *dst = sorted_sym + gbase[c];
+    for (unsigned i = lane; i < len; i += 64) dst[i] = stage[b + i];
+  }
+}
+
 // ------------------------------------------------------------------ K4: state chains
 struct LdsCTable {
   const uint16_t *state_table;
@@ -845,8 +907,13 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.tile_base.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");
-  hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
-                     sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
+  if (M::STREAM == 0)
+    hipLaunchKernelGGL(k_scatter_seq_staged, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+                       sc.tile_hist.as<uint32_t>(), sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
+                       sc.slot_of.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+                       sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
   if (serial_seq) {
