@@ -294,14 +294,14 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
     const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
     const unsigned rank = fq_mbcnt(grp);
     const unsigned cur = cursor[ctx];
-    __syncthreads();  // every lane has read its cursor before any leader advances it
+    fq_lds_wave_sync();  // every lane has read its cursor before any leader advances it
     if (valid) {
       if (rank == 0) cursor[ctx] = cur + (unsigned)__popcll(grp);
       const unsigned slot = cur + rank;
       sorted_sym[slot] = (uint8_t)(key >> 16);
       slot_of[e] = slot;
     }
-    __syncthreads();
+    fq_lds_wave_sync();
   }
 }
 
@@ -350,14 +350,14 @@ k_scatter_seq_staged(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned
     const unsigned long long grp = fq_match_any<SeqModel::KEYBITS>(ctx, valid);
     const unsigned rank = fq_mbcnt(grp);
     const unsigned cur = lcur[ctx];
-    __syncthreads();  // every lane has read its cursor before any leader advances it
+    fq_lds_wave_sync();  // every lane has read its cursor before any leader advances it
     if (valid) {
       if (rank == 0) lcur[ctx] = cur + (unsigned)__popcll(grp);
       const unsigned p = cur + rank;
       stage[p] = (uint8_t)(key >> 16);
       slot_of[e] = gbase[ctx] + (p - lstart[ctx]);
     }
-    __syncthreads();
+    fq_lds_wave_sync();
   }
   // every context's run leaves as one contiguous copy
   for (unsigned c = 0; c < B; c++) {

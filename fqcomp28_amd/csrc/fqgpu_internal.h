@@ -177,6 +177,12 @@ void fq_timer_span_end(fqgpu_ctx *ctx, hipStream_t st);
 
 __device__ __forceinline__ unsigned fq_lane() { return threadIdx.x & 63u; }
 
+// LDS ordering inside ONE wave (single-wave workgroups): the LDS executes a wave's
+// instructions in order, so all that is needed is that earlier LDS operations have completed
+// and that the compiler does not move LDS accesses across this point.  __syncthreads() would
+// also drain vmcnt(0) -- every outstanding global load AND store -- once per loop iteration.
+__device__ __forceinline__ void fq_lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own
 // 4 MiB L2), so with the identity mapping neighbouring tiles never share an L2.  This
 // bijective remap gives every XCD a contiguous range of tiles, walked in order: tiles that
