@@ -283,13 +283,13 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
   for (unsigned c = lane; c < (unsigned)M::B; c += 64) cursor[c] = tile_base[(size_t)tile * M::B + c];
-  unsigned key_next = e0 + lane < e1 ? keys[e0 + lane] : 0u;
+  // Branch-free steady state: every full chunk prefetches the keys of the next one with an
+  // unconditional (clamped) load, so the compiler can count vmcnt instead of draining it; the
+  // ragged last chunk is peeled.
+  const unsigned last = n_sym - 1;
+  unsigned key_next = keys[min(e0 + lane, last)];
   __syncthreads();
-  for (unsigned eb = e0; eb < e1; eb += 64) {
-    const unsigned e = eb + lane;
-    const bool valid = e < e1;
-    const unsigned key = key_next;
-    key_next = e + 64 < e1 ? keys[e + 64] : 0u;  // in flight while this chunk is ranked
+  auto rank_chunk = [&](unsigned e, bool valid, unsigned key) {
     const unsigned ctx = key & 0xFFFFu;
     const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
     const unsigned rank = fq_mbcnt(grp);
@@ -302,7 +302,20 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
       slot_of[e] = slot;
     }
     fq_lds_wave_sync();
+  };
+  // keys are fetched three chunks ahead: vmcnt retires in order, so a wait for the oldest load
+  // also waits for every store issued before the younger loads -- with three loads in flight
+  // the stores it has to wait for are two iterations old and long gone
+  unsigned k1 = keys[min(e0 + 64 + lane, last)], k2 = keys[min(e0 + 128 + lane, last)];
+  unsigned eb = e0;
+  for (; eb + 64 <= e1; eb += 64) {
+    const unsigned e = eb + lane;
+    const unsigned key = key_next;
+    key_next = k1; k1 = k2;
+    k2 = keys[min(e + 192, last)];
+    rank_chunk(e, true, key);
   }
+  if (eb < e1) rank_chunk(eb + lane, eb + lane < e1, key_next);
 }
 
 // Sequence variant of K3 with the tile's partition staged in LDS: the symbols of a tile are
@@ -339,13 +352,10 @@ k_scatter_seq_staged(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned
     run += cnt[k];
   }
   if (lane == 63) lstart[B] = run;
-  unsigned key_next = e0 + lane < e1 ? keys[e0 + lane] : 0u;
+  const unsigned last = n_sym - 1;
+  unsigned key_next = keys[min(e0 + lane, last)];
   __syncthreads();
-  for (unsigned eb = e0; eb < e1; eb += 64) {
-    const unsigned e = eb + lane;
-    const bool valid = e < e1;
-    const unsigned key = key_next;
-    key_next = e + 64 < e1 ? keys[e + 64] : 0u;  // in flight while this chunk is ranked
+  auto rank_chunk = [&](unsigned e, bool valid, unsigned key) {
     const unsigned ctx = key & 0xFFu;
     const unsigned long long grp = fq_match_any<SeqModel::KEYBITS>(ctx, valid);
     const unsigned rank = fq_mbcnt(grp);
@@ -358,7 +368,18 @@ k_scatter_seq_staged(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned
       slot_of[e] = gbase[ctx] + (p - lstart[ctx]);
     }
     fq_lds_wave_sync();
+  };
+  unsigned k1 = keys[min(e0 + 64 + lane, last)], k2 = keys[min(e0 + 128 + lane, last)];  // three chunks ahead
+  unsigned eb = e0;
+  for (; eb + 64 <= e1; eb += 64) {  // branch-free steady state, ragged last chunk peeled
+    const unsigned e = eb + lane;
+    const unsigned key = key_next;
+    key_next = k1; k1 = k2;
+    k2 = keys[min(e + 192, last)];
+    rank_chunk(e, true, key);
   }
+  if (eb < e1) rank_chunk(eb + lane, eb + lane < e1, key_next);
+  fq_lds_wave_sync();
   // every context's run leaves as one contiguous copy
   for (unsigned c = 0; c < B; c++) {
     const unsigned b = lstart[c], len = lstart[c + 1] - b;
