@@ -271,120 +271,103 @@ k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__
 
 // ------------------------------------------------------------------ K3: stable partition by context
 // One wave per tile walks its symbols in encode order, 64 at a time; lanes with equal
-// context are ranked by lane order (ballot match), the group leader advances the
-// context's cursor in LDS.  Stability is what makes every context's run = its chain.
-template <class M>
+// context are ranked by lane order (ballot match), the group leader advances the context's
+// cursor in LDS.  Stability is what makes every context's run = its chain.
+// The ranking loop is a latency chain through LDS (cursor read -> leader write), so it must not
+// contain global memory operations: vmcnt retires in order and hipcc drains it at the loop
+// back-edge, which put one full HBM round trip into every 64-symbol iteration (measured
+// 1.4-2 us).  Keys therefore arrive in batches of SC_BATCH through LDS (one bulk load, many
+// 16-byte requests in flight), the slots of a batch are collected in LDS, and the stores of
+// the batch (coalesced slot_of, scattered sorted_sym) are issued back to back afterwards.
+// STAGED (sequence only): the tile's partition is additionally built in a 32 KB LDS buffer and
+// every context's run leaves as one contiguous copy instead of byte stores.
+constexpr unsigned SC_BATCH = 2048;
+
+template <class M, bool STAGED>
 __global__ void __launch_bounds__(64)
 k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
-          const uint32_t *__restrict__ tile_base, uint8_t *__restrict__ sorted_sym,
-          uint32_t *__restrict__ slot_of) {
-  __shared__ uint32_t cursor[M::B];
+          const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ tile_base,
+          uint8_t *__restrict__ sorted_sym, uint32_t *__restrict__ slot_of) {
+  constexpr unsigned B = M::B;
+  __shared__ uint32_t cursor[B];             // STAGED: local position, else global slot
+  __shared__ uint4 kbatch4[SC_BATCH / 4], sbatch4[SC_BATCH / 4];
+  __shared__ uint8_t stage[STAGED ? TILE_SEQ : 1];
+  __shared__ uint32_t lstart[STAGED ? B + 1 : 1], gbase[STAGED ? B : 1];
+  uint32_t *kbatch = reinterpret_cast<uint32_t *>(kbatch4), *sbatch = reinterpret_cast<uint32_t *>(sbatch4);
   const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
-  for (unsigned c = lane; c < (unsigned)M::B; c += 64) cursor[c] = tile_base[(size_t)tile * M::B + c];
-  // Branch-free steady state: every full chunk prefetches the keys of the next one with an
-  // unconditional (clamped) load, so the compiler can count vmcnt instead of draining it; the
-  // ragged last chunk is peeled.
-  const unsigned last = n_sym - 1;
-  unsigned key_next = keys[min(e0 + lane, last)];
-  __syncthreads();
-  auto rank_chunk = [&](unsigned e, bool valid, unsigned key) {
-    const unsigned ctx = key & 0xFFFFu;
-    const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
-    const unsigned rank = fq_mbcnt(grp);
-    const unsigned cur = cursor[ctx];
-    fq_lds_wave_sync();  // every lane has read its cursor before any leader advances it
-    if (valid) {
-      if (rank == 0) cursor[ctx] = cur + (unsigned)__popcll(grp);
-      const unsigned slot = cur + rank;
-      sorted_sym[slot] = (uint8_t)(key >> 16);
-      slot_of[e] = slot;
+  if (STAGED) {
+    // local layout: exclusive scan of this tile's histogram (B / 64 contexts per lane)
+    constexpr unsigned PER = B / 64;
+    unsigned cnt[PER], sum = 0;
+#pragma unroll
+    for (unsigned k = 0; k < PER; k++) { cnt[k] = tile_hist[(size_t)tile * B + lane * PER + k]; sum += cnt[k]; }
+    unsigned inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(inc, d);
+      if (lane >= (unsigned)d) inc += o;
     }
-    fq_lds_wave_sync();
-  };
-  // keys are fetched three chunks ahead: vmcnt retires in order, so a wait for the oldest load
-  // also waits for every store issued before the younger loads -- with three loads in flight
-  // the stores it has to wait for are two iterations old and long gone
-  unsigned k1 = keys[min(e0 + 64 + lane, last)], k2 = keys[min(e0 + 128 + lane, last)];
-  unsigned eb = e0;
-  for (; eb + 64 <= e1; eb += 64) {
-    const unsigned e = eb + lane;
-    const unsigned key = key_next;
-    key_next = k1; k1 = k2;
-    k2 = keys[min(e + 192, last)];
-    rank_chunk(e, true, key);
-  }
-  if (eb < e1) rank_chunk(eb + lane, eb + lane < e1, key_next);
-}
-
-// Sequence variant of K3 with the tile's partition staged in LDS: the symbols of a tile are
-// grouped by context inside a 32 KB LDS buffer and every context's run leaves as one
-// contiguous copy (128 B on average) instead of 128 byte stores scattered over the walk --
-// the byte-granular scatter of k_scatter completes partial lines in HBM (measured 3.7 GB
-// written for 0.6 GB of payload per 256 MiB block).
-__global__ void __launch_bounds__(64)
-k_scatter_seq_staged(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
-                     const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ tile_base,
-                     uint8_t *__restrict__ sorted_sym, uint32_t *__restrict__ slot_of) {
-  constexpr unsigned B = SeqModel::B;
-  __shared__ uint8_t stage[TILE_SEQ];
-  __shared__ uint32_t lcur[B], lstart[B + 1], gbase[B];
-  const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x;
-  const unsigned e0 = tile * T;
-  const unsigned e1 = min(e0 + T, n_sym);
-  // local layout: exclusive scan of this tile's histogram (4 contexts per lane)
-  unsigned cnt[4], sum = 0;
+    unsigned run = inc - sum;
 #pragma unroll
-  for (int k = 0; k < 4; k++) { cnt[k] = tile_hist[(size_t)tile * B + lane * 4 + k]; sum += cnt[k]; }
-  unsigned inc = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned o = __shfl_up(inc, d);
-    if (lane >= (unsigned)d) inc += o;
-  }
-  unsigned run = inc - sum;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const unsigned c = lane * 4 + k;
-    lstart[c] = run; lcur[c] = run;
-    gbase[c] = tile_base[(size_t)tile * B + c];
-    run += cnt[k];
-  }
-  if (lane == 63) lstart[B] = run;
-  const unsigned last = n_sym - 1;
-  unsigned key_next = keys[min(e0 + lane, last)];
-  __syncthreads();
-  auto rank_chunk = [&](unsigned e, bool valid, unsigned key) {
-    const unsigned ctx = key & 0xFFu;
-    const unsigned long long grp = fq_match_any<SeqModel::KEYBITS>(ctx, valid);
-    const unsigned rank = fq_mbcnt(grp);
-    const unsigned cur = lcur[ctx];
-    fq_lds_wave_sync();  // every lane has read its cursor before any leader advances it
-    if (valid) {
-      if (rank == 0) lcur[ctx] = cur + (unsigned)__popcll(grp);
-      const unsigned p = cur + rank;
-      stage[p] = (uint8_t)(key >> 16);
-      slot_of[e] = gbase[ctx] + (p - lstart[ctx]);
+    for (unsigned k = 0; k < PER; k++) {
+      const unsigned c = lane * PER + k;
+      lstart[c] = run; cursor[c] = run;
+      gbase[c] = tile_base[(size_t)tile * B + c];
+      run += cnt[k];
     }
-    fq_lds_wave_sync();
-  };
-  unsigned k1 = keys[min(e0 + 64 + lane, last)], k2 = keys[min(e0 + 128 + lane, last)];  // three chunks ahead
-  unsigned eb = e0;
-  for (; eb + 64 <= e1; eb += 64) {  // branch-free steady state, ragged last chunk peeled
-    const unsigned e = eb + lane;
-    const unsigned key = key_next;
-    key_next = k1; k1 = k2;
-    k2 = keys[min(e + 192, last)];
-    rank_chunk(e, true, key);
+    if (lane == 63) lstart[B] = run;
+  } else {
+    for (unsigned c = lane; c < B; c += 64) cursor[c] = tile_base[(size_t)tile * B + c];
   }
-  if (eb < e1) rank_chunk(eb + lane, eb + lane < e1, key_next);
   fq_lds_wave_sync();
-  // every context's run leaves as one contiguous copy
-  for (unsigned c = 0; c < B; c++) {
-    const unsigned b = lstart[c], len = lstart[c + 1] - b;
-    uint8_t *dst = sorted_sym + gbase[c];
-    for (unsigned i = lane; i < len; i += 64) dst[i] = stage[b + i];
+  for (unsigned b0 = e0; b0 < e1; b0 += SC_BATCH) {
+    const unsigned nb = min(SC_BATCH, e1 - b0);
+    // bulk load of the batch's keys (keys + b0 is 16-byte aligned; the array is padded)
+    const uint4 *gk = reinterpret_cast<const uint4 *>(keys + b0);
+#pragma unroll
+    for (unsigned i = 0; i < SC_BATCH / 4 / 64; i++) kbatch4[i * 64 + lane] = gk[i * 64 + lane];
+    fq_lds_wave_sync();
+    for (unsigned cb = 0; cb < nb; cb += 64) {  // no global memory operation in here
+      const unsigned i = cb + lane;
+      const bool valid = i < nb;
+      const unsigned key = kbatch[i];
+      const unsigned ctx = key & 0xFFFFu;
+      const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
+      const unsigned rank = fq_mbcnt(grp);
+      const unsigned cur = cursor[ctx];
+      fq_lds_wave_sync();  // every lane has read its cursor before any leader advances it
+      if (valid) {
+        if (rank == 0) cursor[ctx] = cur + (unsigned)__popcll(grp);
+        const unsigned p = cur + rank;
+        if (STAGED) {
+          stage[p] = (uint8_t)(key >> 16);
+          sbatch[i] = gbase[ctx] + (p - lstart[ctx]);
+        } else {
+          sbatch[i] = p;
+        }
+      }
+      fq_lds_wave_sync();
+    }
+    // the batch's stores, back to back
+    uint4 *gs = reinterpret_cast<uint4 *>(slot_of + b0);
+    if (nb == SC_BATCH) {
+#pragma unroll
+      for (unsigned i = 0; i < SC_BATCH / 4 / 64; i++) gs[i * 64 + lane] = sbatch4[i * 64 + lane];
+    } else {
+      for (unsigned i = lane; i < nb; i += 64) slot_of[b0 + i] = sbatch[i];
+    }
+    if (!STAGED)
+      for (unsigned i = lane; i < nb; i += 64) sorted_sym[sbatch[i]] = (uint8_t)(kbatch[i] >> 16);
+    fq_lds_wave_sync();
+  }
+  if (STAGED) {  // every context's run leaves as one contiguous copy
+    for (unsigned c = 0; c < B; c++) {
+      const unsigned b = lstart[c], len = lstart[c + 1] - b;
+      uint8_t *dst = sorted_sym + gbase[c];
+      for (unsigned i = lane; i < len; i += 64) dst[i] = stage[b + i];
+    }
   }
 }
 
@@ -895,8 +878,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   const bool serial_seq = M::STREAM == 0 && !ctx->seq_generic;
 
   int rc;
-  if ((rc = sc.slot_of.reserve((size_t)n_sym * 4))) return rc;
-  if ((rc = sc.keys.reserve((size_t)n_sym * 4))) return rc;
+  if ((rc = sc.slot_of.reserve(((size_t)n_sym + SC_BATCH) * 4))) return rc;
+  if ((rc = sc.keys.reserve(((size_t)n_sym + SC_BATCH) * 4))) return rc;
   if ((rc = sc.sorted_sym.reserve(padded))) return rc;
   if ((rc = sc.out16.reserve(padded * 2))) return rc;
   if ((rc = sc.tile_hist.reserve((size_t)n_tiles * B * 4))) return rc;
@@ -928,13 +911,15 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.tile_base.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");
-  if (M::STREAM == 0)
-    hipLaunchKernelGGL(k_scatter_seq_staged, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
-                       sc.tile_hist.as<uint32_t>(), sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
+  static const bool staged_seq = !getenv("FQGPU_SCATTER_UNSTAGED");
+  if (M::STREAM == 0 && staged_seq)
+    hipLaunchKernelGGL((k_scatter<M, M::STREAM == 0>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym,
+                       T, sc.tile_hist.as<uint32_t>(), sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
                        sc.slot_of.as<uint32_t>());
   else
-    hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
-                       sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
+    hipLaunchKernelGGL((k_scatter<M, false>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+                       sc.tile_hist.as<uint32_t>(), sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
+                       sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
   if (serial_seq) {
