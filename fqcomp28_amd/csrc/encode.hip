@@ -911,7 +911,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.tile_base.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");
-  static const bool staged_seq = !getenv("FQGPU_SCATTER_UNSTAGED");
+  static const bool staged_seq = getenv("FQGPU_SCATTER_STAGED") != nullptr;  // measured slower: 3 vs 9 waves per CU
   if (M::STREAM == 0 && staged_seq)
     hipLaunchKernelGGL((k_scatter<M, M::STREAM == 0>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym,
                        T, sc.tile_hist.as<uint32_t>(), sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
