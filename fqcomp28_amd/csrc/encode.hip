@@ -716,17 +716,33 @@ k_seq_order(const uint32_t *__restrict__ arrays, uint32_t *__restrict__ order) {
 }
 
 // ------------------------------------------------------------------ K6: bit offsets and packing
+// Gathers every symbol's packed (nb, bits) back into encode order ONCE: enc16[e] is written
+// coalesced (it reuses the key buffer, dead after K3) so that the packing pass is a linear read.
 __global__ void __launch_bounds__(PACK_THREADS)
 k_bitcount(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16, unsigned n_sym,
-           uint32_t *__restrict__ tile_bits) {
+           uint32_t *__restrict__ tile_bits, uint16_t *__restrict__ enc16) {
   __shared__ unsigned wsum[PACK_THREADS / 64];
   const unsigned ptile = fq_xcd_tile(blockIdx.x, gridDim.x);
   const unsigned e0 = ptile * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
   unsigned bits = 0;
+  unsigned v[PACK_PER_THREAD];
+  // slot_of / enc16 are padded past n_sym: whole 16-symbol groups can be moved unconditionally
+  const uint4 *sl4 = reinterpret_cast<const uint4 *>(slot_of + e0);
+  unsigned sl[PACK_PER_THREAD];
+#pragma unroll
+  for (unsigned i = 0; i < PACK_PER_THREAD / 4; i++) {
+    const uint4 t = e0 < n_sym ? sl4[i] : make_uint4(0, 0, 0, 0);
+    sl[4 * i] = t.x; sl[4 * i + 1] = t.y; sl[4 * i + 2] = t.z; sl[4 * i + 3] = t.w;
+  }
 #pragma unroll
   for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
-    const unsigned e = e0 + i;
-    if (e < n_sym) bits += out16[slot_of[e]] >> 12;
+    v[i] = e0 + i < n_sym ? (unsigned)out16[sl[i]] : 0u;
+    bits += v[i] >> 12;
+  }
+  if (e0 < n_sym) {
+    uint4 *o4 = reinterpret_cast<uint4 *>(enc16 + e0);
+    o4[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    o4[1] = make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), v[12] | (v[13] << 16), v[14] | (v[15] << 16));
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) bits += __shfl_xor(bits, d);
@@ -761,7 +777,7 @@ k_zero_bounds(const unsigned long long *__restrict__ tile_bit_base, unsigned n_p
 }
 
 __global__ void __launch_bounds__(PACK_THREADS)
-k_pack(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16, unsigned n_sym,
+k_pack(const uint16_t *__restrict__ enc16, unsigned n_sym,
        const unsigned long long *__restrict__ tile_bit_base, uint32_t *__restrict__ out,
        const StreamResult *res) {
   __shared__ uint32_t words[PACK_TILE * 12 / 32 + 4];
@@ -774,11 +790,15 @@ k_pack(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ out16,
   const unsigned e0 = ptile * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
   unsigned v[PACK_PER_THREAD];
   unsigned bits = 0;
+  {
+    const uint4 *i4 = reinterpret_cast<const uint4 *>(enc16 + e0);
+    const uint4 a = e0 < n_sym ? i4[0] : make_uint4(0, 0, 0, 0), b = e0 < n_sym ? i4[1] : make_uint4(0, 0, 0, 0);
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
-    const unsigned e = e0 + i;
-    v[i] = e < n_sym ? (unsigned)out16[slot_of[e]] : 0u;
-    bits += v[i] >> 12;
+    for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
+      v[i] = e0 + i < n_sym ? (w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
+      bits += v[i] >> 12;
+    }
   }
   // exclusive scan of the per-thread bit counts over the workgroup
   unsigned inc = bits;
@@ -956,7 +976,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.bitcount" : "seq.bitcount");
   hipLaunchKernelGGL(k_bitcount, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
-                     sc.out16.as<uint16_t>(), n_sym, sc.tile_bits.as<uint32_t>());
+                     sc.out16.as<uint16_t>(), n_sym, sc.tile_bits.as<uint32_t>(), sc.keys.as<uint16_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.bitscan" : "seq.bitscan");
   if ((rc = fq_scan_u32_to_u64(st, sc.tile_bits.as<uint32_t>(), n_ptiles,
@@ -969,9 +989,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.pack" : "seq.pack");
-  hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
-                     sc.out16.as<uint16_t>(), n_sym, sc.tile_bit_base.as<unsigned long long>(),
-                     reinterpret_cast<uint32_t *>(out_dev), res);
+  hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.keys.as<uint16_t>(), n_sym,
+                     sc.tile_bit_base.as<unsigned long long>(), reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.epilogue" : "seq.epilogue");
   hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, final_state, tab.logs,
