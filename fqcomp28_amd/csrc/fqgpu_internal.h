@@ -198,17 +198,28 @@ __device__ __forceinline__ unsigned fq_mbcnt(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// lanes of the wave holding the same key as the caller (among valid lanes)
+// lanes of the wave holding the same key as the caller (among valid lanes).
+// The partition loops are VALU-bound on this function (SQ counters: 164 VALU instructions per
+// 64-symbol iteration for 13-bit keys), so it is written for instruction count: the per-lane
+// mask is kept as two 32-bit halves of MISMATCH bits, two key bits are folded per v_or3.
 template <int BITS>
 __device__ __forceinline__ unsigned long long fq_match_any(unsigned key, bool valid) {
-  unsigned long long m = __ballot(valid);
+  const unsigned long long vm = __ballot(valid);
+  unsigned mis_lo = 0, mis_hi = 0;  // lanes whose key differs from mine in some bit
 #pragma unroll
-  for (int b = 0; b < BITS; b++) {
-    const bool bit = (key >> b) & 1u;
-    const unsigned long long bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
+  for (int b = 0; b + 1 < BITS; b += 2) {
+    const int m0 = __builtin_amdgcn_sbfe((int)key, b, 1), m1 = __builtin_amdgcn_sbfe((int)key, b + 1, 1);  // 0 / -1
+    const unsigned long long b0 = __ballot(m0 != 0), b1 = __ballot(m1 != 0);
+    mis_lo |= ((unsigned)b0 ^ (unsigned)m0) | ((unsigned)b1 ^ (unsigned)m1);
+    mis_hi |= ((unsigned)(b0 >> 32) ^ (unsigned)m0) | ((unsigned)(b1 >> 32) ^ (unsigned)m1);
   }
-  return m;
+  if (BITS & 1) {
+    const int m0 = __builtin_amdgcn_sbfe((int)key, BITS - 1, 1);
+    const unsigned long long b0 = __ballot(m0 != 0);
+    mis_lo |= (unsigned)b0 ^ (unsigned)m0;
+    mis_hi |= (unsigned)(b0 >> 32) ^ (unsigned)m0;
+  }
+  return vm & ~(((unsigned long long)mis_hi << 32) | mis_lo);
 }
 
 // A0 C1 G2 T3, everything else (N, which the coder treats as A: src/fse_sequence.cpp:44) -> 0
