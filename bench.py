@@ -190,8 +190,18 @@ def main():
     alg_dom = last_bases + stream_out if "." in dom[0] else alg_block
     dom_s = dom[1] / 1e3
     achieved = alg_dom / dom_s / 1e9 if dom_s > 0 else 0.0
+    # HBM bytes of that kernel from the PMC passes committed under profiles/ (separate rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE runs of this script; bench.py cannot collect counters itself)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            tj = json.load(fh)
+        if tj.get("kernel") == dom[0] and args.block_mib == 256:
+            traffic = tj["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                 "avg_launch_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(alg_dom),
                 "launches_timed": calls.get(dom[0], 0),
                 "job_GBps": round(alg_block * len(blocks) * args.steps / elapsed / 1e9, 2),
