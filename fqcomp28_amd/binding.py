@@ -74,6 +74,9 @@ _PROTOS = {
                                      C.c_size_t, C.c_void_p, C.c_size_t]),
     "fqgpu_dblock_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_void_p)]),
+    "fqgpu_dblock_create_from_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "fqgpu_dblock_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_size_t)]),
     "fqgpu_dblock_destroy": (None, [C.c_void_p]),
     "fqgpu_dblock_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint]),
     "fqgpu_dblock_wipe": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -174,15 +177,28 @@ def tables_from_counts(seq_counts, qual_counts, device=0):
 class DBlock:
     """Device-resident block (fqgpu_dblock)."""
 
-    def __init__(self, ctx, raw, recs):
+    def __init__(self, ctx, raw, recs=None):
+        """recs=None: the record table is built on the GPU (fqgpu_dblock_create_from_raw)."""
         raw = np.ascontiguousarray(raw, dtype=np.uint8)
-        recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
         self.ctx = ctx
-        self.raw_len, self.n_recs = raw.size, len(recs)
         h = C.c_void_p()
-        _check(lib().fqgpu_dblock_create(ctx.h, _p(raw), raw.size, _p(recs), len(recs), C.byref(h)),
-               "dblock_create")
-        self.h = h
+        if recs is None:
+            _check(lib().fqgpu_dblock_create_from_raw(ctx.h, _p(raw), raw.size, C.byref(h)), "dblock_create_from_raw")
+            self.h = h
+            n, rl = C.c_size_t(), C.c_size_t()
+            _check(lib().fqgpu_dblock_records(ctx.h, h, None, 0, C.byref(n), C.byref(rl)), "dblock_records")
+            self.raw_len, self.n_recs = rl.value, n.value
+        else:
+            recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+            self.raw_len, self.n_recs = raw.size, len(recs)
+            _check(lib().fqgpu_dblock_create(ctx.h, _p(raw), raw.size, _p(recs), len(recs), C.byref(h)),
+                   "dblock_create")
+            self.h = h
+
+    def records(self):
+        recs = np.zeros(self.n_recs, dtype=REC_DTYPE)
+        _check(lib().fqgpu_dblock_records(self.ctx.h, self.h, _p(recs), self.n_recs, None, None), "dblock_records")
+        return recs
 
     def close(self):
         if getattr(self, "h", None):
@@ -283,7 +299,7 @@ class Context:
         log = int(ct[0] & 0xFFFF)
         return ct[: 1 + (1 << (log - 1)) + 2 * alpha].copy(), dt[: 1 + (1 << log)].copy()
 
-    def dblock(self, raw, recs):
+    def dblock(self, raw, recs=None):
         return DBlock(self, raw, recs)
 
     def decode_dblocks(self, blocks):

@@ -418,6 +418,21 @@ extern "C" void fqgpu_dblock_destroy(fqgpu_dblock *b) {
   delete b;
 }
 
+// stream / side-stream buffers of a block whose raw_len, n_recs, n_bases and n_pos_cap are set
+static int alloc_block_outputs(fqgpu_dblock *b) {
+  b->seq_cap = fqgpu_bound_seq(b->n_bases);
+  b->qual_cap = fqgpu_bound_qual(b->n_bases);
+  b->seq = fq_dev_alloc<uint8_t>(b->seq_cap + 64);
+  b->qual = fq_dev_alloc<uint8_t>(b->qual_cap + 64);
+  b->readlens = fq_dev_alloc<uint16_t>(b->n_recs);
+  b->n_count = fq_dev_alloc<uint16_t>(b->n_recs);
+  b->n_pos = fq_dev_alloc<uint16_t>(b->n_pos_cap + 16);
+  b->result = fq_dev_alloc<BlockResult>(1);
+  if (!b->seq || !b->qual || !b->readlens || !b->n_count || !b->n_pos || !b->result) return FQGPU_E_NOMEM;
+  memset(&b->host_result, 0, sizeof(b->host_result));
+  return FQGPU_OK;
+}
+
 extern "C" int fqgpu_dblock_create(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
                                    size_t n_recs, fqgpu_dblock **out) {
   if (!ctx || !raw || !recs || !out || !n_recs) return FQGPU_E_ARG;
@@ -436,18 +451,10 @@ extern "C" int fqgpu_dblock_create(fqgpu_ctx *ctx, const uint8_t *raw, size_t ra
   if (!b) return FQGPU_E_NOMEM;
   b->device = ctx->device;
   b->raw_len = raw_len; b->n_recs = n_recs; b->n_bases = n_bases;
-  b->seq_cap = fqgpu_bound_seq(n_bases);
-  b->qual_cap = fqgpu_bound_qual(n_bases);
   b->n_pos_cap = n_n;
   b->raw = fq_dev_alloc<uint8_t>(raw_len + 64);
   b->recs = fq_dev_alloc<fqgpu_rec>(n_recs);
-  b->seq = fq_dev_alloc<uint8_t>(b->seq_cap + 64);
-  b->qual = fq_dev_alloc<uint8_t>(b->qual_cap + 64);
-  b->readlens = fq_dev_alloc<uint16_t>(n_recs);
-  b->n_count = fq_dev_alloc<uint16_t>(n_recs);
-  b->n_pos = fq_dev_alloc<uint16_t>(n_n + 16);
-  b->result = fq_dev_alloc<BlockResult>(1);
-  if (!b->raw || !b->recs || !b->seq || !b->qual || !b->readlens || !b->n_count || !b->n_pos || !b->result) {
+  if (!b->raw || !b->recs || alloc_block_outputs(b) != FQGPU_OK) {
     fqgpu_dblock_destroy(b);
     return FQGPU_E_NOMEM;
   }
@@ -456,8 +463,56 @@ extern "C" int fqgpu_dblock_create(fqgpu_ctx *ctx, const uint8_t *raw, size_t ra
   if (he == hipSuccess) he = hipMemsetAsync(b->result, 0, sizeof(BlockResult), ctx->stream);
   if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
   if (he != hipSuccess) { fqgpu_dblock_destroy(b); return fq_hip_error(he, __FILE__, __LINE__); }
-  memset(&b->host_result, 0, sizeof(b->host_result));
   *out = b;
+  return FQGPU_OK;
+}
+
+int fq_parse_on_device(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, DevBuf &scan_tmp,
+                       fqgpu_rec **recs_dev, size_t *n_recs, size_t *n_bases, size_t *n_n);
+
+// Raw block in, record table built on the GPU (parse.hip): replaces FastqReader::parseRecords
+// (reference src/fastq_io.cpp:67-125) for callers that hand over unparsed chunks.
+extern "C" int fqgpu_dblock_create_from_raw(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, fqgpu_dblock **out) {
+  if (!ctx || !raw || !out || !raw_len) return FQGPU_E_ARG;
+  *out = nullptr;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  fqgpu_dblock *b = new (std::nothrow) fqgpu_dblock();
+  if (!b) return FQGPU_E_NOMEM;
+  b->device = ctx->device;
+  b->raw = fq_dev_alloc<uint8_t>(raw_len + 64);
+  if (!b->raw) { fqgpu_dblock_destroy(b); return FQGPU_E_NOMEM; }
+  hipError_t he = hipMemsetAsync(b->raw + raw_len, 0, 64, ctx->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(b->raw, raw, raw_len, hipMemcpyHostToDevice, ctx->stream);
+  if (he != hipSuccess) { fqgpu_dblock_destroy(b); return fq_hip_error(he, __FILE__, __LINE__); }
+  size_t n_n = 0;
+  rc = fq_parse_on_device(ctx->stream, b->raw, raw_len, ctx->scan_tmp, &b->recs, &b->n_recs, &b->n_bases, &n_n);
+  if (rc) { fqgpu_dblock_destroy(b); return rc; }
+  // the block ends with the last complete record (partial tail ignored like the reference)
+  fqgpu_rec last;
+  he = hipMemcpy(&last, b->recs + (b->n_recs - 1), sizeof(last), hipMemcpyDeviceToHost);
+  if (he != hipSuccess) { fqgpu_dblock_destroy(b); return fq_hip_error(he, __FILE__, __LINE__); }
+  b->raw_len = (size_t)last.qual_off + last.len + 1;
+  b->n_pos_cap = n_n;
+  if ((rc = alloc_block_outputs(b))) { fqgpu_dblock_destroy(b); return rc; }
+  he = hipMemsetAsync(b->result, 0, sizeof(BlockResult), ctx->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+  if (he != hipSuccess) { fqgpu_dblock_destroy(b); return fq_hip_error(he, __FILE__, __LINE__); }
+  *out = b;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_records(fqgpu_ctx *ctx, const fqgpu_dblock *b, fqgpu_rec *recs_out, size_t cap,
+                                    size_t *n_recs, size_t *raw_len) {
+  if (!ctx || !b) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  if (n_recs) *n_recs = b->n_recs;
+  if (raw_len) *raw_len = b->raw_len;
+  if (recs_out) {
+    const size_t n = cap < b->n_recs ? cap : b->n_recs;
+    FQ_HIP(hipMemcpy(recs_out, b->recs, n * sizeof(fqgpu_rec), hipMemcpyDeviceToHost));
+  }
   return FQGPU_OK;
 }
 

@@ -139,6 +139,14 @@ int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const
 typedef struct fqgpu_dblock fqgpu_dblock;
 int fqgpu_dblock_create(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
                         size_t n_recs, fqgpu_dblock **out);
+/* Same from an UNPARSED chunk: the record table is built on the GPU (newline scan + 4-line
+ * grouping), replacing FastqReader::parseRecords (src/fastq_io.cpp:67-125), which the reference
+ * runs serially under the reader mutex (src/fastq_io.cpp:29-52).  A trailing partial record is
+ * ignored like the reference's carry-over; malformed input returns FQGPU_E_ARG. */
+int fqgpu_dblock_create_from_raw(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, fqgpu_dblock **out);
+/* record table / size of a block (any pointer may be NULL; at most cap records are copied) */
+int fqgpu_dblock_records(fqgpu_ctx *ctx, const fqgpu_dblock *b, fqgpu_rec *recs_out, size_t cap,
+                         size_t *n_recs, size_t *raw_len);
 void fqgpu_dblock_destroy(fqgpu_dblock *b);
 /* asynchronous on the handle's stream; sizes are valid after fqgpu_sync() */
 int fqgpu_dblock_encode(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags);

@@ -372,3 +372,37 @@ def test_cpp_workspace_shim_roundtrip(golden_dir):
     out = subprocess.run([exe] + files, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok ") == len(files)
+
+
+# ---------------------------------------------------------------- next row: GPU FASTQ record parser
+def test_gpu_parser_matches_cpu_parser(F, golden_dir):
+    """fqgpu_dblock_create_from_raw (newline scan + 4-line grouping on the GPU) against the host
+    parser and the numpy restatement of FastqReader::parseRecords (src/fastq_io.cpp:67-125)."""
+    raw0, recs0 = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_1.fastq"))
+    _, _, sft, qft = O.freq_tables(raw0, recs0)
+    ctx = F.Context(sft, qft)
+    cases = [raw0, raw0[: raw0.size - 23]]  # whole block; block with a partial record at the end
+    for mode in (2, 4):
+        cases.append(F.synth_fastq(3 << 20, mode)[0])
+    for raw in cases:
+        want = F.parse_fastq(raw)
+        b = ctx.dblock(raw)  # no record table handed over
+        got = b.records()
+        assert np.array_equal(got, want)
+        assert b.raw_len == int(want[-1]["qual_off"] + want[-1]["len"] + 1)
+        b.close()
+    # an unparsed block encodes to the same streams as the parsed one
+    e = O.OracleCtx(sft, qft).encode(raw0, recs0)
+    b = ctx.dblock(raw0)
+    b.encode()
+    ctx.sync()
+    g = b.fetch()
+    for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+        assert np.array_equal(g[k], e[k]), k
+    b.close()
+    # malformed input is refused
+    for bad in (b"@r\nACGT\n-\nIIII\n", b"@r\nACGT\n+\nIII\n", b"r\nACGT\n+\nIIII\n", b"@r\nAC\n+\nII\n", b"no newline"):
+        with pytest.raises(F.FqgpuError) as ei:
+            ctx.dblock(np.frombuffer(bad, dtype=np.uint8))
+        assert ei.value.code in (-4, -2)
+    ctx.close()
