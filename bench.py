@@ -254,6 +254,27 @@ def main():
         for b in sdb:
             b.close()
 
+    # ---- the callers either side of the path (not part of `value`): host-pointer call incl. PCIe
+    # and per-call buffers, and the GPU record parser against the host parser
+    if rank == 0 and not args.skip_decode:
+        raw0, recs0 = blocks[0]
+        t0 = time.perf_counter()
+        got = ctx.encode_block(raw0, recs0)
+        dt = time.perf_counter() - t0
+        assert got["rc"] == 0
+        extra["host_pointer_encode_MBps"] = round(raw0.size / dt / MB, 1)
+        t0 = time.perf_counter()
+        hr = F.parse_fastq(raw0)
+        t_host = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pb = ctx.dblock(raw0)  # H2D + newline scan + record table on the GPU
+        ctx.sync()
+        t_gpu = time.perf_counter() - t0
+        ok = bool(np.array_equal(pb.records(), hr))
+        pb.close()
+        extra["parser"] = {"host_parse_MBps": round(raw0.size / t_host / MB, 1),
+                           "gpu_create_from_raw_MBps_incl_h2d": round(raw0.size / t_gpu / MB, 1), "tables_equal": ok}
+
     cpu = None
     if rank == 0 and world == 1 and not args.skip_cpu:
         cpu = cpu_baseline(blocks, sft, qft)
