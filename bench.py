@@ -103,8 +103,9 @@ def main():
     ap.add_argument("--decode-block-mib", type=int, default=1, help="block size of the many-blocks decode run")
     ap.add_argument("--decode-mib", type=int, default=256, help="data decoded in the many-blocks run")
     ap.add_argument("--lanes", type=int, default=4, help="blocks in flight per GPU (encode lanes)")
-    ap.add_argument("--seq-mode", default="all2", choices=["split", "all2", "one", "generic"],
-                    help="sequence chain kernels: long chains two symbols/step (default), all two, all one, reset-cut")
+    ap.add_argument("--seq-mode", default="two", choices=["two", "one", "generic"],
+                    help="sequence chain kernels: two symbols per step (default), one, reset-cut kernel")
+    ap.add_argument("--seq-part", type=int, default=None, help="part length of split sequence chains (symbols)")
     ap.add_argument("--skip-decode", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     args = ap.parse_args()
@@ -135,7 +136,7 @@ def main():
     ctx = F.Context(sft, qft, device=device)
     ctx.set_lanes(max(1, min(args.lanes, 8)))
     ctx.set_chain_params(0, seq_generic=args.seq_mode == "generic", seq_one_symbol=args.seq_mode == "one",
-                         seq_all_t2=args.seq_mode == "all2")
+                         seq_part_target=args.seq_part)
     dblocks = [ctx.dblock(raw, recs) for raw, recs in blocks]
     raw_bytes = sum(raw.size for raw, _ in blocks)
     n_recs = sum(len(r) for _, r in blocks)

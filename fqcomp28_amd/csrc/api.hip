@@ -158,7 +158,6 @@ EncLane *fq_next_lane(fqgpu_ctx *ctx) {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&l.st_seq, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&l.st_qual, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&l.st_hot, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&l.ev_scat, hipEventDisableTiming) != hipSuccess ||
@@ -174,7 +173,7 @@ static void free_lane(EncLane &l) {
   for (int s = 0; s < 2; s++) {
     EncScratch &e = l.enc[s];
     DevBuf *eb[] = {&e.slot_of, &e.keys, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
-                    &e.ctx_arrays, &e.seg_state, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
+                    &e.ctx_arrays, &e.seg_state, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
     for (DevBuf *b : eb) b->release();
   }
   hipEvent_t evs[] = {l.ev_fork, l.ev_join, l.ev_scat, l.ev_hot};
@@ -372,7 +371,12 @@ extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsi
   }
   ctx->seq_generic = (flags & FQGPU_CHAIN_SEQ_GENERIC) ? 1 : 0;
   ctx->seq_one_symbol = (flags & FQGPU_CHAIN_SEQ_ONE_SYMBOL) ? 1 : 0;
-  ctx->seq_all_t2 = (flags & FQGPU_CHAIN_SEQ_LONG_TWO_SYMBOL) ? 0 : 1;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_ctx_set_seq_part_target(fqgpu_ctx *ctx, unsigned symbols) {
+  if (!ctx) return FQGPU_E_ARG;
+  ctx->seq_part_target = symbols;
   return FQGPU_OK;
 }
 

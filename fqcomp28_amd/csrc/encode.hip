@@ -40,6 +40,8 @@ constexpr unsigned PACK_TILE = 4096;   // symbols per bit-packing tile
 constexpr unsigned PACK_THREADS = 256;
 constexpr unsigned PACK_PER_THREAD = PACK_TILE / PACK_THREADS;  // 16
 constexpr unsigned CTX_PAD = 16;       // every context's sorted run starts 16-aligned
+constexpr unsigned FQ_MAX_LOG_SEQ = 12;  // FSE_MAX_TABLELOG: slot size of a composed function
+constexpr unsigned FQ_MAX_LOG_T2 = 11;   // two-symbol table only up to this log (64 KB)
 
 template <class M> constexpr unsigned tile_size() { return M::STREAM == 0 ? TILE_SEQ : TILE_QUAL; }
 
@@ -527,102 +529,248 @@ k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ ou
   atomicMax(&res->refixed, steps);  // longest serial run (diagnostic)
 }
 
-// Sequence chains: one workgroup of two waves per context.  A chain step on the critical path
-// is one add and one 2-byte LDS read (measured 62.5 shader cycles = 26 ns,
-// tools/chain_ubench.hip): the transition table is expanded to next[s][x - size] in LDS
-// (4 << log u16 entries, pre-scaled to byte offsets).  Software pipeline over chunks of
-// SEQ_CHUNK symbols, double-buffered in LDS:
-//   wave 0, lane 0 : walks chunk k LDS -> LDS, recording only the state in front of every symbol
-//   wave 1         : turns (state, symbol) of chunk k-1 into the packed (nb, bits) outputs and
-//                    stores them with coalesced 16-byte stores, then stages the symbols of
-//                    chunk k+1 with coalesced 16-byte loads
-// so the chain lane never waits on global memory and never computes an output.
-constexpr unsigned SEQ_CHUNK = 4096;
-constexpr unsigned SEQ_HOT_MAX = 16;  // at most this many chains per block take the two-symbol kernel
+// ---- sequence chains -------------------------------------------------------------------
+// Sequence contexts have no single-state symbols, so a chain cannot be cut "for free".  Two
+// exact tools are used instead:
+//  (1) the per-step latency: the transition table is expanded in LDS so that a step is one add
+//      and one 2-byte LDS read (62.5 shader cycles = 26 ns, tools/chain_ubench.hip), two symbols
+//      per step through T2[s2][s1][x] (64 KB at log 11);
+//  (2) function composition: the effect of a chunk of symbols on the state is a function
+//      F: {0..size-1} -> {0..size-1}.  k_seq_compose computes F for every 4096-symbol chunk of
+//      the leading parts of a LONG chain by walking all `size` states through the chunk (256
+//      lanes x 8 states, LDS-throughput-bound, all chunks in parallel); k_seq_apply chains the
+//      F's (one lookup per chunk) and so obtains the exact start state of every part.  Long
+//      chains (context 0xD7 also receives the first base of every read: 2.7x the average) are
+//      thereby split into parts of about the average chain length that are walked concurrently.
+constexpr unsigned COMPOSE_CHUNK = 4096;  // symbols per composed function; parts are multiples of it
 
-// a chain is "hot" when it is among the SEQ_HOT_MAX longest and 25 % above the average length
-__device__ __forceinline__ bool seq_chain_is_hot(unsigned n, unsigned rank, unsigned n_sym) {
-  if (n_sym == 0) return true;  // "every chain takes the two-symbol kernel" mode
-  return rank < SEQ_HOT_MAX && (unsigned long long)n * 4ull * SeqModel::B > (unsigned long long)n_sym * 5ull;
+struct SeqPart {
+  uint32_t ctx, begin, len;  // symbols [begin, begin + len) of the context's run
+  uint32_t start_xo;         // (state - size) * 2 in front of symbol `begin`
+  uint32_t last;             // this part ends the chain: it owns final_state[ctx]
+};
+
+// plan[]: n_parts | n_compose_chunks | cprefix[B + 1] (compose chunks before every context)
+//         | eprefix[B + 1] (parts before every context) | cpp[B] (compose chunks per part)
+constexpr unsigned PLAN_WORDS = 2 + 3 * SeqModel::B + 2;
+
+__global__ void __launch_bounds__(256)
+k_seq_plan(const uint32_t *__restrict__ arrays, unsigned n_sym, unsigned target, uint32_t *__restrict__ plan,
+           SeqPart *__restrict__ parts) {
+  constexpr unsigned B = SeqModel::B;
+  __shared__ unsigned s_comp[B], s_parts[B];
+  const unsigned c = threadIdx.x;
+  const unsigned n = arrays[c];
+  // target part length: the average chain of this block (at least one compose chunk)
+  unsigned L = target ? target : max(n_sym / B, COMPOSE_CHUNK);
+  L = ((L + COMPOSE_CHUNK - 1) / COMPOSE_CHUNK) * COMPOSE_CHUNK;
+  unsigned P = 1, plen = n;
+  if (n > L + L / 8) {  // worth splitting: more than 12.5 % above the target
+    P = (n + L - 1) / L;
+    plen = (((n + P - 1) / P + COMPOSE_CHUNK - 1) / COMPOSE_CHUNK) * COMPOSE_CHUNK;
+    P = (n + plen - 1) / plen;
+  }
+  if (n == 0) P = 0;
+  const unsigned cpp = P > 1 ? plen / COMPOSE_CHUNK : 0;
+  s_parts[c] = P;
+  s_comp[c] = P > 1 ? (P - 1) * cpp : 0;
+  __syncthreads();
+  unsigned ep = 0, cp = 0;
+  for (unsigned o = 0; o < c; o++) { ep += s_parts[o]; cp += s_comp[o]; }
+  uint32_t *cprefix = plan + 2, *eprefix = cprefix + B + 1, *cpps = eprefix + B + 1;
+  cprefix[c] = cp; eprefix[c] = ep; cpps[c] = cpp;
+  if (c == B - 1) {
+    cprefix[B] = cp + s_comp[c]; eprefix[B] = ep + s_parts[c];
+    plan[0] = ep + s_parts[c]; plan[1] = cp + s_comp[c];
+  }
+  for (unsigned p = 0; p < P; p++) {
+    SeqPart q;
+    q.ctx = c; q.begin = p * plen; q.len = min(plen, n - p * plen);
+    q.start_xo = 0; q.last = (p == P - 1);
+    parts[ep + p] = q;
+  }
+}
+
+// one-symbol transition table of a context in LDS: next[s][x - size] = (state after s) - size,
+// pre-scaled to the byte offset of the following lookup
+__device__ __forceinline__ void build_next1(uint16_t *next, const uint32_t *__restrict__ tbl, unsigned log,
+                                            unsigned nthreads) {
+  const unsigned size = 1u << log;
+  const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
+  const uint32_t *tt = tbl + 1 + (size >> 1);
+  for (unsigned e = threadIdx.x; e < 4 * size; e += nthreads) {
+    const unsigned s = e >> log, xi = e & (size - 1), x = size + xi;
+    const unsigned nb = (x + tt[2 * s + 1]) >> 16;
+    next[e] = (uint16_t)(((unsigned)st[(int)(x >> nb) + (int)tt[2 * s]] - size) * 2u);
+  }
+}
+
+// F of one chunk: all `size` states walked through its COMPOSE_CHUNK symbols.
+// One workgroup of 256 threads per chunk, up to 16 states per thread (size <= 4096).
+__global__ void __launch_bounds__(256)
+k_seq_compose(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
+              const uint32_t *__restrict__ plan, const uint32_t *__restrict__ ct,
+              const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ fbuf) {
+  extern __shared__ uint32_t lds[];
+  __shared__ uint4 symbuf[COMPOSE_CHUNK / 16];
+  constexpr unsigned B = SeqModel::B;
+  const unsigned g = blockIdx.x;
+  if (g >= plan[1]) return;  // the grid is an upper bound
+  const uint32_t *cprefix = plan + 2;
+  unsigned lo = 0, hi = B - 1;  // context owning compose chunk g
+  while (lo < hi) {
+    const unsigned mid = lo + ((hi - lo + 1) >> 1);
+    if (cprefix[mid] <= g) lo = mid; else hi = mid - 1;
+  }
+  const unsigned c = lo, j = g - cprefix[c];
+  const uint32_t *tbl = ct + ct_off[c];
+  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
+  uint16_t *next = reinterpret_cast<uint16_t *>(lds);
+  build_next1(next, tbl, log, 256);
+  const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)j * COMPOSE_CHUNK);
+  symbuf[threadIdx.x] = gsym[threadIdx.x];  // 256 threads x 16 symbols
+  __syncthreads();
+  const char *nbase = reinterpret_cast<const char *>(next);
+  const unsigned per = max(size >> 8, 1u);  // states per thread
+  unsigned x[16];
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++) x[k] = ((threadIdx.x * per + k) & (size - 1)) * 2u;
+  for (unsigned v = 0; v < COMPOSE_CHUNK / 16; v++) {
+    const uint4 sv = symbuf[v];  // same address in every lane: LDS broadcast
+    const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const unsigned row = ((w[i >> 2] >> (8 * (i & 3))) & 3u) << (log + 1);
+#pragma unroll
+      for (unsigned k = 0; k < 16; k++)
+        if (k < per) x[k] = *reinterpret_cast<const uint16_t *>(nbase + (row + x[k]));
+    }
+  }
+  uint16_t *f = fbuf + (size_t)g * (1u << FQ_MAX_LOG_SEQ);
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++)
+    if (k < per && threadIdx.x * per + k < size) f[threadIdx.x * per + k] = (uint16_t)x[k];
+}
+
+// start state of every part of every split chain: x <- F_chunk[x], chunk after chunk
+__global__ void __launch_bounds__(256)
+k_seq_apply(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, SeqPart *__restrict__ parts) {
+  constexpr unsigned B = SeqModel::B;
+  const unsigned c = threadIdx.x;
+  const uint32_t *cprefix = plan + 2, *eprefix = cprefix + B + 1, *cpps = eprefix + B + 1;
+  const unsigned n_comp = cprefix[c + 1] - cprefix[c], cpp = cpps[c];
+  if (n_comp == 0) return;
+  unsigned xo = 0;  // FSE_initCState: state = size
+  for (unsigned j = 0; j < n_comp; j++) {
+    xo = fbuf[(size_t)(cprefix[c] + j) * (1u << FQ_MAX_LOG_SEQ) + (xo >> 1)];
+    if ((j + 1) % cpp == 0) parts[eprefix[c] + (j + 1) / cpp].start_xo = xo;
+  }
 }
 
 // (state, symbol) -> (nb << 12 | low nb bits of the state) for 8 consecutive symbols of a
 // chunk; states come from statebuf (every symbol: STRIDE 1; every even symbol: STRIDE 2, the
-// odd ones are recomputed through the one-symbol table `next`)
+// odd ones are recomputed with one transition straight from the L1-resident CTable)
 template <int STRIDE>
-__device__ __forceinline__ uint4 seq_outputs8(const uint8_t *sbytes, const uint16_t *statebuf, const char *nbase,
-                                              unsigned v, unsigned log, unsigned size, const unsigned *dnb) {
+__device__ __forceinline__ uint4 seq_outputs8(const uint8_t *sbytes, const uint16_t *statebuf,
+                                              const uint16_t *__restrict__ st, const int *dfs, unsigned v,
+                                              unsigned size, const unsigned *dnb) {
   unsigned o[4];
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
     const unsigned i = v * 8 + j;
     const unsigned s1 = sbytes[i] & 3u, s2 = sbytes[i + 1] & 3u;
-    const unsigned xo1 = statebuf[STRIDE == 1 ? i : (i >> 1)];
-    const unsigned xo2 = STRIDE == 1 ? (unsigned)statebuf[i + 1]
-                                     : (unsigned)*reinterpret_cast<const uint16_t *>(nbase + ((s1 << (log + 1)) + xo1));
-    const unsigned x1 = size + (xo1 >> 1), x2 = size + (xo2 >> 1);
-    const unsigned nb1 = (x1 + (s1 == 0 ? dnb[0] : s1 == 1 ? dnb[1] : s1 == 2 ? dnb[2] : dnb[3])) >> 16;
+    const unsigned x1 = size + ((unsigned)statebuf[STRIDE == 1 ? i : (i >> 1)] >> 1);
+    const unsigned d1 = s1 == 0 ? dnb[0] : s1 == 1 ? dnb[1] : s1 == 2 ? dnb[2] : dnb[3];
+    const unsigned nb1 = (x1 + d1) >> 16;
+    unsigned x2;
+    if (STRIDE == 1) {
+      x2 = size + ((unsigned)statebuf[i + 1] >> 1);
+    } else {
+      const int f1 = s1 == 0 ? dfs[0] : s1 == 1 ? dfs[1] : s1 == 2 ? dfs[2] : dfs[3];
+      x2 = st[(int)(x1 >> nb1) + f1];  // FSE_encodeSymbol's state update
+    }
     const unsigned nb2 = (x2 + (s2 == 0 ? dnb[0] : s2 == 1 ? dnb[1] : s2 == 2 ? dnb[2] : dnb[3])) >> 16;
     o[j >> 1] = ((nb1 << 12) | (x1 & ((1u << nb1) - 1u))) | (((nb2 << 12) | (x2 & ((1u << nb2) - 1u))) << 16);
   }
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// TWO = false: one symbol per step.  TWO = true: two symbols per step through
-// T2[s2][s1][x - size] (16 << log u16 entries, 64 KB at log 11), for the few long chains.
+// The walker: one workgroup of two waves per PART.  Software pipeline over chunks, double-
+// buffered in LDS:
+//   wave 0, lane 0 : walks chunk k LDS -> LDS, recording only the state in front of every
+//                    (TWO: every even) symbol; raised issue priority
+//   wave 1         : turns (state, symbol) of chunk k-1 into the packed (nb, bits) outputs and
+//                    stores them with coalesced 16-byte stores, then stages the symbols of
+//                    chunk k+1 (coalesced 16-byte loads) and their table-row offsets
+// so the chain lane never waits on global memory and never computes an output.
+// TWO = false: one symbol per step (16 KB table).  TWO = true: two symbols per step through
+// T2 (64 KB at log 11; LDS footprint 76 KB -> two workgroups per CU).
 template <bool TWO>
 __global__ void __launch_bounds__(128)
 k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-            const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ order, unsigned n_sym,
-            const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
-            uint16_t *__restrict__ final_state, StreamResult *res) {
+            const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ plan,
+            const SeqPart *__restrict__ parts, const uint32_t *__restrict__ ct,
+            const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state, StreamResult *res) {
+  constexpr unsigned CH = TWO ? 2048 : 4096;  // symbols per pipeline chunk
   extern __shared__ uint32_t lds[];
-  __shared__ uint4 symbuf[2][SEQ_CHUNK / 16];
-  __shared__ uint16_t statebuf[2][TWO ? SEQ_CHUNK / 2 : SEQ_CHUNK];  // (state - size) * 2
+  __shared__ uint4 symbuf[2][CH / 16];
+  __shared__ uint16_t statebuf[2][TWO ? CH / 2 : CH];  // (state - size) * 2
   // byte offset of the table row every step reads: (symbol or symbol pair) << (log + 1),
   // prepared by the helper wave so the walker's step is add + LDS read and nothing else
-  __shared__ uint16_t offbuf[2][TWO ? SEQ_CHUNK / 2 : SEQ_CHUNK];
+  __shared__ uint16_t offbuf[2][TWO ? CH / 2 : CH];
   constexpr unsigned B = SeqModel::B;
-  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B;
-  // order[0..B) = contexts by descending chain length, order[B..2B) = rank of every context
-  const unsigned c = TWO ? order[blockIdx.x] : blockIdx.x;
-  const unsigned n = ctx_count[c];
-  if (n == 0) return;
-  if (TWO) { if (!seq_chain_is_hot(n, blockIdx.x, n_sym)) return; }
-  else if (order && seq_chain_is_hot(n, order[B + c], n_sym)) return;  // the two-symbol kernel walks it
+  if (blockIdx.x >= plan[0]) return;  // the grid is an upper bound
+  const SeqPart part = parts[blockIdx.x];
+  const unsigned c = part.ctx, n = part.len;
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
   const uint32_t *tbl = ct + ct_off[c];
   const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
   const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
   const uint32_t *tt = tbl + 1 + (size >> 1);
-  uint16_t *next = reinterpret_cast<uint16_t *>(lds);  // [4][size]
-  uint16_t *t2 = next + 4 * size;                      // [16][size] (TWO only)
   unsigned dnb[4];
+  int dfs[4];
 #pragma unroll
-  for (int s = 0; s < 4; s++) dnb[s] = tt[2 * s + 1];
-  for (unsigned e = threadIdx.x; e < 4 * size; e += 128) {
-    const unsigned s = e >> log, xi = e & (size - 1), x = size + xi;
-    const unsigned nb = (x + tt[2 * s + 1]) >> 16;
-    next[e] = (uint16_t)(((unsigned)st[(int)(x >> nb) + (int)tt[2 * s]] - size) * 2u);
-  }
-  __syncthreads();
-  const char *nbase = reinterpret_cast<const char *>(next);
-  if (TWO) {
-    for (unsigned e = threadIdx.x; e < 16 * size; e += 128) {
+  for (int s = 0; s < 4; s++) { dfs[s] = (int)tt[2 * s]; dnb[s] = tt[2 * s + 1]; }
+  uint16_t *table = reinterpret_cast<uint16_t *>(lds);  // ONE: next[4][size]; TWO: T2[16][size]
+  if (!TWO) {
+    build_next1(table, tbl, log, 128);
+  } else {
+    // T2 is built from the one-symbol table, which is parked in the LAST quarter of the T2
+    // area: the first three quarters are written while it is read, the last quarter is computed
+    // into registers, and only then overwritten
+    uint16_t *next = table + 12 * size;
+    build_next1(next, tbl, log, 128);
+    __syncthreads();
+    const char *nb1 = reinterpret_cast<const char *>(next);
+    auto t2_entry = [&](unsigned e) -> uint16_t {
       const unsigned xi = e & (size - 1), s1 = (e >> log) & 3u, s2 = e >> (log + 2);
       const unsigned mid = next[(s1 << log) + xi];
-      t2[e] = *reinterpret_cast<const uint16_t *>(nbase + ((s2 << (log + 1)) + mid));
+      return *reinterpret_cast<const uint16_t *>(nb1 + ((s2 << (log + 1)) + mid));
+    };
+    for (unsigned e = threadIdx.x; e < 12 * size; e += 128) table[e] = t2_entry(e);
+    uint16_t keep[(4u << FQ_MAX_LOG_T2) / 128];
+#pragma unroll
+    for (unsigned k = 0; k < (4u << FQ_MAX_LOG_T2) / 128; k++) {
+      const unsigned e = 12 * size + k * 128 + threadIdx.x;
+      keep[k] = e < 16 * size ? t2_entry(e) : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < (4u << FQ_MAX_LOG_T2) / 128; k++) {
+      const unsigned e = 12 * size + k * 128 + threadIdx.x;
+      if (e < 16 * size) table[e] = keep[k];
     }
   }
-  const char *tbase = reinterpret_cast<const char *>(t2);
-  const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + ctx_start[c]);  // 16-byte aligned (CTX_PAD)
-  uint4 *gout = reinterpret_cast<uint4 *>(out16 + ctx_start[c]);
-  const unsigned n_chunks = (n + SEQ_CHUNK - 1) / SEQ_CHUNK;
+  const char *tbase = reinterpret_cast<const char *>(table);
+  const size_t run0 = (size_t)arrays[B + c] + part.begin;  // 16-byte aligned (CTX_PAD, COMPOSE_CHUNK)
+  const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + run0);
+  uint4 *gout = reinterpret_cast<uint4 *>(out16 + run0);
+  const unsigned n_chunks = (n + CH - 1) / CH;
   // symbols of chunk kn -> symbuf + row offsets (the run is padded to 16: reading the pad is harmless)
   auto stage = [&](unsigned kn) {
-    const unsigned q16 = (min(SEQ_CHUNK, n - kn * SEQ_CHUNK) + 15) >> 4;
+    const unsigned q16 = (min(CH, n - kn * CH) + 15) >> 4;
     for (unsigned v = lane; v < q16; v += 64) {
-      const uint4 sv = gsym[kn * (SEQ_CHUNK / 16) + v];
+      const uint4 sv = gsym[kn * (CH / 16) + v];
       symbuf[kn & 1][v] = sv;
       const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
       unsigned o[8];
@@ -647,14 +795,22 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
   };
   if (wave == 1) stage(0);  // prologue
   __syncthreads();
-  unsigned xo = 0;  // (state - size) * 2, meaningful in wave 0 lane 0 only
+  unsigned xo = part.start_xo;  // (state - size) * 2, meaningful in wave 0 lane 0 only
   // the walker is the critical path of the whole block: it wins issue arbitration against
   // whatever else shares its SIMD
   if (wave == 0) __builtin_amdgcn_s_setprio(3);
+  // one FSE_encodeSymbol transition straight from the CTable (ragged tail only)
+  auto step1 = [&](unsigned s, unsigned cur) -> unsigned {
+    const unsigned x = size + (cur >> 1);
+    const unsigned d = s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3];
+    const int f = s == 0 ? dfs[0] : s == 1 ? dfs[1] : s == 2 ? dfs[2] : dfs[3];
+    const unsigned nb = (x + d) >> 16;
+    return ((unsigned)st[(int)(x >> nb) + f] - size) * 2u;
+  };
   for (unsigned k = 0; k <= n_chunks; k++) {
     if (wave == 0) {
       if (lane == 0 && k < n_chunks) {
-        const unsigned len = min(SEQ_CHUNK, n - k * SEQ_CHUNK);
+        const unsigned len = min(CH, n - k * CH);
         const unsigned q16 = (len + 15) >> 4, full = len >> 4;
         const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf[k & 1]);
         uint16_t *stb = statebuf[k & 1];
@@ -684,7 +840,7 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
 #pragma unroll
             for (int j = 0; j < 16; j++) {
               xs[j] = xo;
-              xo = *reinterpret_cast<const uint16_t *>(nbase + (((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + xo));
+              xo = *reinterpret_cast<const uint16_t *>(tbase + (((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + xo));
             }
             state4[2 * g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
             state4[2 * g + 1] = make_uint4(xs[8] | (xs[9] << 16), xs[10] | (xs[11] << 16), xs[12] | (xs[13] << 16), xs[14] | (xs[15] << 16));
@@ -697,41 +853,26 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
           const unsigned s = sbytes[i] & 3u;
           if (!TWO) stb[i] = (uint16_t)xo;
           else if (!(i & 1u)) stb[i >> 1] = (uint16_t)xo;
-          xo = *reinterpret_cast<const uint16_t *>(nbase + ((s << (log + 1)) + xo));
+          xo = step1(s, xo);
         }
       }
     } else {
       if (k >= 1) {  // outputs of chunk k-1
         const unsigned kk = k - 1;
-        const unsigned len = min(SEQ_CHUNK, n - kk * SEQ_CHUNK);
+        const unsigned len = min(CH, n - kk * CH);
         const unsigned q8 = (len + 7) >> 3;
         const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf[kk & 1]);
         for (unsigned v = lane; v < q8; v += 64)
-          gout[kk * (SEQ_CHUNK / 8) + v] = seq_outputs8<TWO ? 2 : 1>(sbytes, statebuf[kk & 1], nbase, v, log, size, dnb);
+          gout[kk * (CH / 8) + v] = seq_outputs8<TWO ? 2 : 1>(sbytes, statebuf[kk & 1], st, dfs, v, size, dnb);
       }
       if (k + 1 < n_chunks) stage(k + 1);  // into the buffers whose outputs were just produced
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    final_state[c] = (uint16_t)(size + (xo >> 1));
+    if (part.last) final_state[c] = (uint16_t)(size + (xo >> 1));
     atomicMax(&res->refixed, n);
   }
-}
-
-// longest chains first (context 0xD7 also receives the first base of every read): order[0..B)
-// = contexts by descending length, order[B..2B) = rank of every context
-__global__ void __launch_bounds__(256)
-k_seq_order(const uint32_t *__restrict__ arrays, uint32_t *__restrict__ order) {
-  __shared__ uint32_t cnt[SeqModel::B];
-  const unsigned c = threadIdx.x;
-  cnt[c] = arrays[c];
-  __syncthreads();
-  const unsigned mine = cnt[c];
-  unsigned rank = 0;
-  for (unsigned o = 0; o < (unsigned)SeqModel::B; o++) rank += (cnt[o] > mine) || (cnt[o] == mine && o < c);
-  order[rank] = c;
-  order[SeqModel::B + c] = rank;
 }
 
 // ------------------------------------------------------------------ K6: bit offsets and packing
@@ -926,6 +1067,10 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if ((rc = sc.group_sum.reserve((size_t)n_groups * B * 4))) return rc;
   if ((rc = sc.ctx_arrays.reserve((size_t)(4 * B + 3) * 4))) return rc;
   if ((rc = sc.seg_state.reserve((size_t)B * 2 + (size_t)B * 8))) return rc;
+  if (M::STREAM == 0) {
+    if ((rc = sc.seq_plan.reserve((size_t)PLAN_WORDS * 4 + ((size_t)B + n_sym / COMPOSE_CHUNK + 2) * sizeof(SeqPart)))) return rc;
+    if ((rc = sc.seq_fbuf.reserve(((size_t)n_sym / COMPOSE_CHUNK + 2) * (2u << FQ_MAX_LOG_SEQ)))) return rc;
+  }
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
   if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
 
@@ -962,31 +1107,31 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
   if (serial_seq) {
-    uint32_t *order = reinterpret_cast<uint32_t *>(final_state + B);
-    const unsigned lds1 = 8u << tab.max_log, lds2 = 40u << tab.max_log;
-    const bool can_two = tab.max_log <= 11 && !ctx->seq_one_symbol;
-    hipLaunchKernelGGL(k_seq_order, dim3(1), dim3(256), 0, st, arrays, order);
-    if (can_two && ctx->seq_all_t2) {
-      hipLaunchKernelGGL(k_chain_seq<true>, dim3(B), dim3(128), lds2, st, sc.sorted_sym.as<uint8_t>(),
-                         sc.out16.as<uint16_t>(), arrays, order, 0u, tab.ct, tab.ct_off, final_state, res);
-    } else if (can_two) {
-      // the few long chains: two symbols per step (64 KB table each) on the lane's third stream,
-      // everything else: one symbol per step (16 KB table) here -- both kernels run side by side
-      FQ_HIP(hipEventRecord(lane.ev_scat, st));
-      FQ_HIP(hipStreamWaitEvent(lane.st_hot, lane.ev_scat, 0));
-      fq_timer_span_begin(ctx, "seq.chains.hot", lane.st_hot);
-      hipLaunchKernelGGL(k_chain_seq<true>, dim3(SEQ_HOT_MAX), dim3(128), lds2, lane.st_hot,
-                         sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, order, n_sym, tab.ct,
-                         tab.ct_off, final_state, res);
-      fq_timer_span_end(ctx, lane.st_hot);
-      FQ_HIP(hipEventRecord(lane.ev_hot, lane.st_hot));
-      hipLaunchKernelGGL(k_chain_seq<false>, dim3(B), dim3(128), lds1, st, sc.sorted_sym.as<uint8_t>(),
-                         sc.out16.as<uint16_t>(), arrays, order, n_sym, tab.ct, tab.ct_off, final_state, res);
-      FQ_HIP(hipStreamWaitEvent(st, lane.ev_hot, 0));
-    } else {
-      hipLaunchKernelGGL(k_chain_seq<false>, dim3(B), dim3(128), lds1, st, sc.sorted_sym.as<uint8_t>(),
-                         sc.out16.as<uint16_t>(), arrays, (const uint32_t *)nullptr, n_sym, tab.ct, tab.ct_off,
-                         final_state, res);
+    // plan: long chains are split into parts of about the average chain length; the start
+    // state of every part comes from composed chunk functions (k_seq_compose / k_seq_apply)
+    uint32_t *plan = sc.seq_plan.as<uint32_t>();
+    SeqPart *parts = reinterpret_cast<SeqPart *>(plan + PLAN_WORDS);
+    const unsigned max_comp = n_sym / COMPOSE_CHUNK + 1;
+    // same rounding as k_seq_plan: upper bound of the number of parts
+    unsigned part_len = ctx->seq_part_target ? ctx->seq_part_target : max(n_sym / B, COMPOSE_CHUNK);
+    part_len = ((part_len + COMPOSE_CHUNK - 1) / COMPOSE_CHUNK) * COMPOSE_CHUNK;
+    const unsigned max_parts = B + n_sym / part_len + 1;
+    uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
+    const bool two = tab.max_log <= FQ_MAX_LOG_T2 && !ctx->seq_one_symbol;
+    static const bool dbg_skip = getenv("FQGPU_DEBUG_SKIP_SEQ_CHAIN") != nullptr;  // timing experiment only: wrong output
+    hipLaunchKernelGGL(k_seq_plan, dim3(1), dim3(256), 0, st, arrays, n_sym, ctx->seq_part_target, plan, parts);
+    if (!dbg_skip) {
+      hipLaunchKernelGGL(k_seq_compose, dim3(max_comp), dim3(256), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
+                         arrays, plan, tab.ct, tab.ct_off, fbuf);
+      hipLaunchKernelGGL(k_seq_apply, dim3(1), dim3(256), 0, st, plan, fbuf, parts);
+      if (two)
+        hipLaunchKernelGGL(k_chain_seq<true>, dim3(max_parts), dim3(128), 32u << tab.max_log, st,
+                           sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, plan, parts, tab.ct,
+                           tab.ct_off, final_state, res);
+      else
+        hipLaunchKernelGGL(k_chain_seq<false>, dim3(max_parts), dim3(128), 8u << tab.max_log, st,
+                           sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, plan, parts, tab.ct,
+                           tab.ct_off, final_state, res);
     }
   } else {
     hipLaunchKernelGGL(k_chains_reset<M>, dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),

@@ -98,7 +98,9 @@ struct EncScratch {
   DevBuf tile_base;   // u32 [tiles][B]
   DevBuf group_sum;   // u32 [groups][B]
   DevBuf ctx_arrays;  // ctx_count[B], ctx_start[B+1], seg_base[B+1], item_base[B+1]
-  DevBuf seg_state;   // u16 spec_start[nsegmax], u16 seg_end[nsegmax]
+  DevBuf seg_state;   // u16 final_state[B]
+  DevBuf seq_plan;    // plan words + SeqPart[2B] (sequence stream: parts of split chains)
+  DevBuf seq_fbuf;    // u16 [compose chunks][4096] composed chunk functions
   DevBuf tile_bits;   // u32 [ptiles]
   DevBuf tile_bit_base;  // u64 [ptiles+1]
   DevBuf scan_tmp;    // u64 chunk sums for the scans
@@ -125,7 +127,7 @@ struct fqgpu_ctx {
   unsigned seg_len = 1024;       // nominal segment of the reset-cut chain kernel
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
   int seq_one_symbol = 0;        // 1: serial sequence kernel with one symbol per step (no T2 table)
-  int seq_all_t2 = 1;            // 1: every sequence chain takes the two-symbol kernel (default); 0: only the long ones
+  unsigned seq_part_target = 0;  // part length of split sequence chains (0 = average chain of the block)
   unsigned n_lanes = 4, next_lane = 0;
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch

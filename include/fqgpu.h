@@ -91,8 +91,11 @@ void fqgpu_ctx_destroy(fqgpu_ctx *ctx);
  * one symbol per step with FQGPU_CHAIN_SEQ_ONE_SYMBOL or when a table log exceeds 11). */
 #define FQGPU_CHAIN_SEQ_GENERIC 1u
 #define FQGPU_CHAIN_SEQ_ONE_SYMBOL 2u /* serial sequence kernel without the two-symbol table */
-#define FQGPU_CHAIN_SEQ_LONG_TWO_SYMBOL 4u /* two-symbol table only for the few long chains (third stream), one-symbol for the rest */
 int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned flags);
+/* Sequence chains longer than ~1.125x `symbols` are split into parts of about that length whose
+ * exact start states come from composed chunk functions (0 = the block's average chain length;
+ * rounded up to a multiple of 4096).  Results never depend on it. */
+int fqgpu_ctx_set_seq_part_target(fqgpu_ctx *ctx, unsigned symbols);
 /* Number of blocks the handle keeps in flight (encode lanes, 1..8, default 4): each
  * fqgpu_dblock_encode goes to the next lane (own HIP streams and scratch). */
 int fqgpu_ctx_set_lanes(fqgpu_ctx *ctx, unsigned lanes);

@@ -133,13 +133,13 @@ def test_tables_from_counts_normalisation_corner_cases(F):
 
 # ---------------------------------------------------------------- how the chains are cut never shows in the output
 @pytest.mark.parametrize("seg,seq_generic,lanes", [(2, True, 1), (16, True, 3), (64, False, 2), (100000, True, 1),
-                                                   (1024, False, 4), (1024, "one", 2), (1024, "split", 2)])
+                                                   (1024, False, 4), (1024, "one", 2)])
 def test_chain_parameters_never_change_the_bits(F, golden_dir, seg, seq_generic, lanes):
     raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_2.fastq"))
     _, _, sft, qft = O.freq_tables(raw, recs)
     e = O.OracleCtx(sft, qft).encode(raw, recs)
     ctx = F.Context(sft, qft)
-    ctx.set_chain_params(seg, seq_generic is True, seq_generic == "one", seq_all_t2=seq_generic != "split")
+    ctx.set_chain_params(seg, seq_generic is True, seq_generic == "one")
     ctx.set_lanes(lanes)
     blocks = [ctx.dblock(raw, recs) for _ in range(3)]  # several blocks in flight on the lanes
     for b in blocks:
@@ -193,6 +193,21 @@ def test_config1_uniform_q40_degenerate_context(F):
     rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, O.blank_skeleton(raw, recs))
     assert rc == 0 and np.array_equal(out, raw)
     ctx.close()
+
+
+@pytest.mark.parametrize("part_target", [4096, 20000, 1 << 30])
+def test_split_sequence_chains_are_exact(F, part_target):
+    """Long sequence chains are split into parts whose start states come from composed chunk
+    functions (k_seq_compose / k_seq_apply): any part length gives the same bits."""
+    raw, recs = _synth(F, 2, 6 << 20)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    for one_symbol in (False, True):
+        ctx = F.Context(sft, qft)
+        ctx.set_chain_params(0, seq_one_symbol=one_symbol, seq_part_target=part_target)
+        g = ctx.encode_block(raw, recs)
+        assert_same_encoding(g, e)
+        ctx.close()
 
 
 @pytest.mark.parametrize("mode,size", [(2, 12 << 20), (4, 12 << 20)])
