@@ -711,7 +711,7 @@ k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16
             const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ plan,
             const SeqPart *__restrict__ parts, const uint32_t *__restrict__ ct,
             const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state, StreamResult *res) {
-  constexpr unsigned CH = TWO ? 2048 : 4096;  // symbols per pipeline chunk
+  constexpr unsigned CH = TWO ? 2048 : 1024;  // symbols per pipeline chunk (ONE: 26 KB of LDS -> 6 workgroups per CU)
   extern __shared__ uint32_t lds[];
   __shared__ uint4 symbuf[2][CH / 16];
   __shared__ uint16_t statebuf[2][TWO ? CH / 2 : CH];  // (state - size) * 2
@@ -915,25 +915,54 @@ k_bitcount(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ ou
   }
 }
 
-// size and overflow verdict once the payload bit count is known
-// (BIT_closeCStream: 0 when the write pointer reached dst+cap-8, zstd bitstream.h)
-__global__ void k_finalize(const unsigned long long *__restrict__ tile_bit_base, unsigned n_ptiles,
-                           const uint32_t *__restrict__ log_prefix, unsigned B,
-                           unsigned long long cap, StreamResult *res) {
-  const unsigned long long payload = tile_bit_base[n_ptiles];
+// Bit offsets of the packing tiles, size/overflow verdict and zeroing of the words shared by two
+// tiles, in ONE single-workgroup kernel: the per-tile counts are few (M / 4096) and every extra
+// launch on a block's critical path costs its scheduling latency on a busy GPU (measured ~0.8 ms
+// per tiny kernel when four blocks are in flight).
+// Verdict = BIT_closeCStream: 0 when the write pointer reached dst+cap-8 (zstd bitstream.h).
+__global__ void __launch_bounds__(1024)
+k_bitscan(const uint32_t *__restrict__ tile_bits, unsigned n_ptiles, unsigned long long *__restrict__ tile_bit_base,
+          const uint32_t *__restrict__ log_prefix, unsigned B, unsigned long long cap, uint32_t *__restrict__ out,
+          StreamResult *res) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
+  for (unsigned base = 0; base < n_ptiles; base += 1024) {
+    const unsigned i = base + threadIdx.x;
+    const unsigned long long v = i < n_ptiles ? tile_bits[i] : 0ull;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long o = __shfl_up(inc, d);
+      if (lane >= (unsigned)d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long off = s_carry;
+    for (unsigned w = 0; w < wave; w++) off += wsum[w];
+    if (i < n_ptiles) tile_bit_base[i] = off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = off + inc;
+    __syncthreads();
+  }
+  const unsigned long long payload = s_carry;
   const unsigned long long all = payload + log_prefix[B] + 1ull;  // + state flush + end mark
-  res->total_bits = payload;
-  res->len = (all + 7ull) >> 3;
-  res->overflow = (cap <= 8ull || (all >> 3) >= cap - 8ull) ? 1u : 0u;
-}
-
-// words shared by two packing tiles are OR-ed into, so they start from zero
-__global__ void __launch_bounds__(256)
-k_zero_bounds(const unsigned long long *__restrict__ tile_bit_base, unsigned n_ptiles,
-              uint32_t *__restrict__ out, const StreamResult *res) {
-  if (res->overflow) return;
-  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t <= n_ptiles) out[tile_bit_base[t] >> 5] = 0u;
+  const bool overflow = cap <= 8ull || (all >> 3) >= cap - 8ull;
+  if (threadIdx.x == 0) {
+    tile_bit_base[n_ptiles] = payload;
+    res->total_bits = payload;
+    res->len = (all + 7ull) >> 3;
+    res->overflow = overflow ? 1u : 0u;
+  }
+  if (overflow) return;
+  __syncthreads();  // tile_bit_base of this workgroup's own writes
+  // words shared by two packing tiles are OR-ed into, so they start from zero
+  for (unsigned t = threadIdx.x; t <= n_ptiles; t += 1024) {
+    const unsigned long long b = t < n_ptiles ? tile_bit_base[t] : payload;
+    out[b >> 5] = 0u;
+  }
 }
 
 __global__ void __launch_bounds__(PACK_THREADS)
@@ -1081,7 +1110,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   (void)pfx;
 
   FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");
-  static const unsigned hist_threads_q = getenv("FQGPU_HIST_THREADS") ? (unsigned)atoi(getenv("FQGPU_HIST_THREADS")) : 1024u;
+  static const unsigned hist_threads_q = getenv("FQGPU_HIST_THREADS") ? (unsigned)atoi(getenv("FQGPU_HIST_THREADS")) : 256u;
   hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(M::STREAM ? hist_threads_q : 256), 0, st, b->raw, b->recs,
                      rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), sc.keys.as<uint32_t>(), res);
   FQ_SPAN_END();
@@ -1143,13 +1172,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.out16.as<uint16_t>(), n_sym, sc.tile_bits.as<uint32_t>(), sc.keys.as<uint16_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.bitscan" : "seq.bitscan");
-  if ((rc = fq_scan_u32_to_u64(st, sc.tile_bits.as<uint32_t>(), n_ptiles,
-                               sc.tile_bit_base.as<unsigned long long>(), sc.scan_tmp)))
-    return rc;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1), 0, st, sc.tile_bit_base.as<unsigned long long>(),
-                     n_ptiles, tab.log_prefix, B, (unsigned long long)cap, res);
-  hipLaunchKernelGGL(k_zero_bounds, dim3((n_ptiles + 256) / 256), dim3(256), 0, st,
-                     sc.tile_bit_base.as<unsigned long long>(), n_ptiles,
+  hipLaunchKernelGGL(k_bitscan, dim3(1), dim3(1024), 0, st, sc.tile_bits.as<uint32_t>(), n_ptiles,
+                     sc.tile_bit_base.as<unsigned long long>(), tab.log_prefix, B, (unsigned long long)cap,
                      reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.pack" : "seq.pack");
@@ -1190,8 +1214,7 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
   FQ_SPAN_BEGIN("records");
   hipLaunchKernelGGL(k_readlens_ncount, dim3(rec_blocks), dim3(256), 0, st, b->raw, b->recs, R,
                      b->readlens, b->n_count, n_cnt32, lens32);
-  if ((rc = fq_scan_u32_to_u32(st, lens32, R, rec_start, lane.scan_tmp))) return rc;
-  if ((rc = fq_scan_u32_to_u32(st, n_cnt32, R, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
+  if ((rc = fq_scan2_u32_to_u32(st, lens32, n_cnt32, R, rec_start, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
   hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
   FQ_SPAN_END();
 

@@ -168,6 +168,8 @@ int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);
 
 // generic exclusive scans (scan.hip): out has n+1 entries, out[n] = total
 int fq_scan_u32_to_u32(hipStream_t st, const uint32_t *in, size_t n, uint32_t *out, DevBuf &tmp);
+int fq_scan2_u32_to_u32(hipStream_t st, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out_a,
+                        uint32_t *out_b, DevBuf &tmp);
 int fq_scan_u32_to_u64(hipStream_t st, const uint32_t *in, size_t n, unsigned long long *out, DevBuf &tmp);
 
 // kernel timing hooks (api.hip): HIP events on the stream the kernels are launched on

@@ -89,6 +89,61 @@ k_chunk_scan(const uint32_t *__restrict__ in, size_t n, const unsigned long long
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (OutT)sums[n_chunks];
 }
 
+// two arrays of the same length scanned by the same three launches (record lengths and N counts)
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_chunk_sums2(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n,
+              unsigned long long *__restrict__ sums_a, unsigned long long *__restrict__ sums_b) {
+  const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+  unsigned long long va = 0, vb = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    const size_t idx = base + (size_t)i * SCAN_THREADS + threadIdx.x;
+    if (idx < n) { va += a[idx]; vb += b[idx]; }
+  }
+  unsigned long long ta, tb;
+  (void)block_excl_scan(va, &ta);
+  (void)block_excl_scan(vb, &tb);
+  if (threadIdx.x == 0) { sums_a[blockIdx.x] = ta; sums_b[blockIdx.x] = tb; }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_sums2(unsigned long long *__restrict__ sums_a, unsigned long long *__restrict__ sums_b, size_t n_chunks) {
+  unsigned long long ca = 0, cb = 0;
+  for (size_t base = 0; base < n_chunks; base += SCAN_THREADS) {
+    const size_t idx = base + threadIdx.x;
+    const unsigned long long va = idx < n_chunks ? sums_a[idx] : 0ull, vb = idx < n_chunks ? sums_b[idx] : 0ull;
+    unsigned long long ta, tb;
+    const unsigned long long ea = block_excl_scan(va, &ta);
+    const unsigned long long eb = block_excl_scan(vb, &tb);
+    if (idx < n_chunks) { sums_a[idx] = ca + ea; sums_b[idx] = cb + eb; }
+    ca += ta; cb += tb;
+  }
+  if (threadIdx.x == 0) { sums_a[n_chunks] = ca; sums_b[n_chunks] = cb; }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_chunk_scan2(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n,
+              const unsigned long long *__restrict__ sums_a, const unsigned long long *__restrict__ sums_b,
+              size_t n_chunks, uint32_t *__restrict__ out_a, uint32_t *__restrict__ out_b) {
+  const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t xa[SCAN_ITEMS], xb[SCAN_ITEMS];
+  unsigned long long va = 0, vb = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    xa[i] = (base + i < n) ? a[base + i] : 0u; va += xa[i];
+    xb[i] = (base + i < n) ? b[base + i] : 0u; vb += xb[i];
+  }
+  unsigned long long ta, tb;
+  unsigned long long ra = sums_a[blockIdx.x] + block_excl_scan(va, &ta);
+  unsigned long long rb = sums_b[blockIdx.x] + block_excl_scan(vb, &tb);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < n) { out_a[base + i] = (uint32_t)ra; out_b[base + i] = (uint32_t)rb; }
+    ra += xa[i]; rb += xb[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out_a[n] = (uint32_t)sums_a[n_chunks]; out_b[n] = (uint32_t)sums_b[n_chunks]; }
+}
+
 template <class OutT>
 int scan_impl(hipStream_t st, const uint32_t *in, size_t n, OutT *out, DevBuf &tmp) {
   const size_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -104,6 +159,20 @@ int scan_impl(hipStream_t st, const uint32_t *in, size_t n, OutT *out, DevBuf &t
 }
 
 }  // namespace
+
+int fq_scan2_u32_to_u32(hipStream_t st, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out_a,
+                        uint32_t *out_b, DevBuf &tmp) {
+  const size_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  const size_t nc = n_chunks ? n_chunks : 1;
+  int rc = tmp.reserve(2 * (nc + 1) * sizeof(unsigned long long));
+  if (rc) return rc;
+  unsigned long long *sa = tmp.as<unsigned long long>(), *sb = sa + nc + 1;
+  hipLaunchKernelGGL(k_chunk_sums2, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, a, b, n, sa, sb);
+  hipLaunchKernelGGL(k_scan_sums2, dim3(1), dim3(SCAN_THREADS), 0, st, sa, sb, nc);
+  hipLaunchKernelGGL(k_chunk_scan2, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, a, b, n, sa, sb, nc, out_a, out_b);
+  FQ_HIP(hipGetLastError());
+  return FQGPU_OK;
+}
 
 int fq_scan_u32_to_u32(hipStream_t st, const uint32_t *in, size_t n, uint32_t *out, DevBuf &tmp) {
   return scan_impl<uint32_t>(st, in, n, out, tmp);
