@@ -1134,7 +1134,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                        sc.tile_hist.as<uint32_t>(), sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
                        sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : "seq.chains");
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : (serial_seq ? "seq.compose" : "seq.chains"));
   if (serial_seq) {
     // plan: long chains are split into parts of about the average chain length; the start
     // state of every part comes from composed chunk functions (k_seq_compose / k_seq_apply)
@@ -1153,6 +1153,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
       hipLaunchKernelGGL(k_seq_compose, dim3(max_comp), dim3(256), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
                          arrays, plan, tab.ct, tab.ct_off, fbuf);
       hipLaunchKernelGGL(k_seq_apply, dim3(1), dim3(256), 0, st, plan, fbuf, parts);
+      FQ_SPAN_END();
+      FQ_SPAN_BEGIN("seq.chains");
       if (two)
         hipLaunchKernelGGL(k_chain_seq<true>, dim3(max_parts), dim3(128), 32u << tab.max_log, st,
                            sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, plan, parts, tab.ct,
