@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--seq-mode", default="two", choices=["two", "one", "generic"],
                     help="sequence chain kernels: two symbols per step (default), one, reset-cut kernel")
     ap.add_argument("--seq-part", type=int, default=None, help="part length of split sequence chains (symbols)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank); gloo only to rehearse the "
+                    "multi-rank path on a one-GPU box (all ranks then share GPU 0)")
     ap.add_argument("--skip-decode", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     args = ap.parse_args()
@@ -117,8 +119,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        if args.dist_backend == "gloo":
+            local = 0  # rehearsal: every rank on GPU 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     import fqcomp28_amd as F
     from fqcomp28_amd.farm import reduce_max, reduce_sum
     assert F.device_count() > local, "bench.py needs a GPU (no CPU fallback)"
