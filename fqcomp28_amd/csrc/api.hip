@@ -8,7 +8,7 @@
 #include <new>
 #include <vector>
 
-// The encode lanes use up to 12 streams (three per block in flight: sequence, quality, long chains).  ROCm maps streams onto
+// The encode lanes use up to 16 streams (two per block in flight: sequence and quality pipelines).  ROCm maps streams onto
 // GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
 // run back to back; ask for 12 before the runtime initialises (no effect if the host
 // application already initialised HIP or set the variable itself).
@@ -159,9 +159,7 @@ EncLane *fq_next_lane(fqgpu_ctx *ctx) {
     if (hipStreamCreateWithPriority(&l.st_seq, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&l.st_qual, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&l.ev_scat, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&l.ev_hot, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming) != hipSuccess)
       return nullptr;
   }
   return &l;
@@ -176,9 +174,9 @@ static void free_lane(EncLane &l) {
                     &e.ctx_arrays, &e.seg_state, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
     for (DevBuf *b : eb) b->release();
   }
-  hipEvent_t evs[] = {l.ev_fork, l.ev_join, l.ev_scat, l.ev_hot};
+  hipEvent_t evs[] = {l.ev_fork, l.ev_join};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-  hipStream_t sts[] = {l.st_seq, l.st_qual, l.st_hot};
+  hipStream_t sts[] = {l.st_seq, l.st_qual};
   for (hipStream_t q : sts) if (q) (void)hipStreamDestroy(q);
   l = EncLane();
 }
@@ -542,7 +540,6 @@ extern "C" int fqgpu_sync(fqgpu_ctx *ctx) {
   for (int i = 0; i < FQ_MAX_LANES; i++) {
     if (ctx->lanes[i].st_seq) FQ_HIP(hipStreamSynchronize(ctx->lanes[i].st_seq));
     if (ctx->lanes[i].st_qual) FQ_HIP(hipStreamSynchronize(ctx->lanes[i].st_qual));
-    if (ctx->lanes[i].st_hot) FQ_HIP(hipStreamSynchronize(ctx->lanes[i].st_hot));
   }
   if (ctx->stream) FQ_HIP(hipStreamSynchronize(ctx->stream));
   return FQGPU_OK;

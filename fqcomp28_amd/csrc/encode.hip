@@ -282,57 +282,30 @@ k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__
 // 1.4-2 us).  Keys therefore arrive in batches of SC_BATCH through LDS (one bulk load, many
 // 16-byte requests in flight), the slots of a batch are collected in LDS, and the stores of
 // the batch (coalesced slot_of, scattered sorted_sym) are issued back to back afterwards.
-// STAGED (sequence only): the tile's partition is additionally built in a 32 KB LDS buffer and
-// every context's run leaves as one contiguous copy instead of byte stores.
+// (Staging the tile's partition in LDS to write whole runs was measured SLOWER: the 32 KB buffer
+// costs two thirds of the occupancy and the loop is VALU-bound on the ballot match, not on stores.)
 constexpr unsigned SC_BATCH = 2048;
 
-template <class M, bool STAGED>
+template <class M>
 __global__ void __launch_bounds__(64)
 k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
-          const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ tile_base,
-          uint8_t *__restrict__ sorted_sym, uint32_t *__restrict__ slot_of) {
+          const uint32_t *__restrict__ tile_base, uint8_t *__restrict__ sorted_sym,
+          uint32_t *__restrict__ slot_of) {
   constexpr unsigned B = M::B;
   // REL (many contexts): 16-bit cursors relative to the tile's base (a tile has at most 65536
-  // symbols), 16 KB instead of 32 KB of LDS -> 5 instead of 3 waves per CU; the base is added
-  // from the (L2-resident) tile_base row when the batch is stored
-  constexpr bool REL = !STAGED && B > 1024;
+  // symbols), 16 KB instead of 32 KB of LDS; the base is added from the (L2-resident) tile_base
+  // row when the batch is stored
+  constexpr bool REL = B > 1024;
   using cur_t = typename std::conditional<REL, uint16_t, uint32_t>::type;
-  __shared__ cur_t cursor[B];                // STAGED: local position, REL: rank inside the tile, else global slot
+  __shared__ cur_t cursor[B];  // REL: rank inside the tile, else global slot
   __shared__ uint4 kbatch4[SC_BATCH / 4], sbatch4[REL ? SC_BATCH / 8 : SC_BATCH / 4];
-  __shared__ uint8_t stage[STAGED ? TILE_SEQ : 1];
-  __shared__ uint32_t lstart[STAGED ? B + 1 : 1], gbase[STAGED ? B : 1];
   uint32_t *kbatch = reinterpret_cast<uint32_t *>(kbatch4), *sbatch = reinterpret_cast<uint32_t *>(sbatch4);
   uint16_t *rbatch = reinterpret_cast<uint16_t *>(sbatch4);
-  const uint32_t *tb_row = tile_base + (size_t)fq_xcd_tile(blockIdx.x, gridDim.x) * B;
   const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x;
+  const uint32_t *tb_row = tile_base + (size_t)tile * B;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
-  if (STAGED) {
-    // local layout: exclusive scan of this tile's histogram (B / 64 contexts per lane)
-    constexpr unsigned PER = B / 64;
-    unsigned cnt[PER], sum = 0;
-#pragma unroll
-    for (unsigned k = 0; k < PER; k++) { cnt[k] = tile_hist[(size_t)tile * B + lane * PER + k]; sum += cnt[k]; }
-    unsigned inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned o = __shfl_up(inc, d);
-      if (lane >= (unsigned)d) inc += o;
-    }
-    unsigned run = inc - sum;
-#pragma unroll
-    for (unsigned k = 0; k < PER; k++) {
-      const unsigned c = lane * PER + k;
-      lstart[c] = run; cursor[c] = run;
-      gbase[c] = tile_base[(size_t)tile * B + c];
-      run += cnt[k];
-    }
-    if (lane == 63) lstart[B] = run;
-  } else if (REL) {
-    for (unsigned c = lane; c < B; c += 64) cursor[c] = 0;
-  } else {
-    for (unsigned c = lane; c < B; c += 64) cursor[c] = (cur_t)tile_base[(size_t)tile * B + c];
-  }
+  for (unsigned c = lane; c < B; c += 64) cursor[c] = REL ? (cur_t)0 : (cur_t)tb_row[c];
   fq_lds_wave_sync();
   for (unsigned b0 = e0; b0 < e1; b0 += SC_BATCH) {
     const unsigned nb = min(SC_BATCH, e1 - b0);
@@ -344,51 +317,49 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
     for (unsigned cb = 0; cb < nb; cb += 64) {  // no global memory operation in here
       const unsigned i = cb + lane;
       const bool valid = i < nb;
-      const unsigned key = kbatch[i];
-      const unsigned ctx = key & 0xFFFFu;
+      const unsigned ctx = kbatch[i] & 0xFFFFu;
       const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
       const unsigned rank = fq_mbcnt(grp);
       const unsigned cur = cursor[ctx];
       fq_lds_wave_sync();  // every lane has read its cursor before any leader advances it
       if (valid) {
         if (rank == 0) cursor[ctx] = (cur_t)(cur + (unsigned)__popcll(grp));
-        const unsigned p = cur + rank;
-        if (STAGED) {
-          stage[p] = (uint8_t)(key >> 16);
-          sbatch[i] = gbase[ctx] + (p - lstart[ctx]);
-        } else if (REL) {
-          rbatch[i] = (uint16_t)p;
-        } else {
-          sbatch[i] = p;
-        }
+        if (REL) rbatch[i] = (uint16_t)(cur + rank); else sbatch[i] = cur + rank;
       }
       fq_lds_wave_sync();
     }
     // the batch's stores, back to back
-    uint4 *gs = reinterpret_cast<uint4 *>(slot_of + b0);
     if (REL) {
-      for (unsigned i = lane; i < nb; i += 64) {
-        const unsigned key = kbatch[i];
-        const unsigned slot = tb_row[key & 0xFFFFu] + rbatch[i];
-        slot_of[b0 + i] = slot;
-        sorted_sym[slot] = (uint8_t)(key >> 16);
-      }
-    } else if (nb == SC_BATCH) {
+      if (nb == SC_BATCH) {
+        // all gathers of the tile_base row first (one wait), then the stores: a load between
+        // two stores would wait for the older store (vmcnt retires in order)
+        unsigned slots[SC_BATCH / 64];
 #pragma unroll
-      for (unsigned i = 0; i < SC_BATCH / 4 / 64; i++) gs[i * 64 + lane] = sbatch4[i * 64 + lane];
+        for (unsigned j = 0; j < SC_BATCH / 64; j++) slots[j] = tb_row[kbatch[j * 64 + lane] & 0xFFFFu] + rbatch[j * 64 + lane];
+#pragma unroll
+        for (unsigned j = 0; j < SC_BATCH / 64; j++) {
+          slot_of[b0 + j * 64 + lane] = slots[j];
+          sorted_sym[slots[j]] = (uint8_t)(kbatch[j * 64 + lane] >> 16);
+        }
+      } else {
+        for (unsigned i = lane; i < nb; i += 64) {
+          const unsigned key = kbatch[i];
+          const unsigned slot = tb_row[key & 0xFFFFu] + rbatch[i];
+          slot_of[b0 + i] = slot;
+          sorted_sym[slot] = (uint8_t)(key >> 16);
+        }
+      }
     } else {
-      for (unsigned i = lane; i < nb; i += 64) slot_of[b0 + i] = sbatch[i];
-    }
-    if (!STAGED && !REL)
+      uint4 *gs = reinterpret_cast<uint4 *>(slot_of + b0);
+      if (nb == SC_BATCH) {
+#pragma unroll
+        for (unsigned i = 0; i < SC_BATCH / 4 / 64; i++) gs[i * 64 + lane] = sbatch4[i * 64 + lane];
+      } else {
+        for (unsigned i = lane; i < nb; i += 64) slot_of[b0 + i] = sbatch[i];
+      }
       for (unsigned i = lane; i < nb; i += 64) sorted_sym[sbatch[i]] = (uint8_t)(kbatch[i] >> 16);
-    fq_lds_wave_sync();
-  }
-  if (STAGED) {  // every context's run leaves as one contiguous copy
-    for (unsigned c = 0; c < B; c++) {
-      const unsigned b = lstart[c], len = lstart[c + 1] - b;
-      uint8_t *dst = sorted_sym + gbase[c];
-      for (unsigned i = lane; i < len; i += 64) dst[i] = stage[b + i];
     }
+    fq_lds_wave_sync();
   }
 }
 
@@ -1124,15 +1095,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.tile_base.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");
-  static const bool staged_seq = getenv("FQGPU_SCATTER_STAGED") != nullptr;  // measured slower: 3 vs 9 waves per CU
-  if (M::STREAM == 0 && staged_seq)
-    hipLaunchKernelGGL((k_scatter<M, M::STREAM == 0>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym,
-                       T, sc.tile_hist.as<uint32_t>(), sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
-                       sc.slot_of.as<uint32_t>());
-  else
-    hipLaunchKernelGGL((k_scatter<M, false>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
-                       sc.tile_hist.as<uint32_t>(), sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(),
-                       sc.slot_of.as<uint32_t>());
+  hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+                     sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : (serial_seq ? "seq.compose" : "seq.chains"));
   if (serial_seq) {

@@ -107,10 +107,11 @@ struct EncScratch {
 };
 
 // One encode lane: everything a block needs while it is being coded, so that several
-// blocks can be in flight on one GPU (two HIP streams: sequence and quality pipelines).
+// blocks can be in flight on one GPU (two HIP streams: sequence pipeline at high priority,
+// quality pipeline at low priority).
 struct EncLane {
-  hipStream_t st_seq = nullptr, st_qual = nullptr, st_hot = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scat = nullptr, ev_hot = nullptr;
+  hipStream_t st_seq = nullptr, st_qual = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevBuf rec_start;   // u32 [R+1] first encode index of each record
   DevBuf n_cnt32;     // u32 [R] N count | u32 [R] length
   DevBuf n_off;       // u32 [R+1]
