@@ -61,10 +61,8 @@ __device__ __forceinline__ unsigned peek_bits(const uint32_t *w, long long lo, u
   return (unsigned)(v >> (unsigned)(lo & 31)) & ((1u << nb) - 1u);
 }
 
-constexpr unsigned DEC_LINE = 512;  // output bytes buffered in LDS between two coalesced copies
-
 template <class M>
-__device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *state, uint32_t *dt_off, uint8_t *line) {
+__device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *state, uint32_t *dt_off) {
   constexpr unsigned B = M::B;
   const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
@@ -87,49 +85,40 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *sta
     dt_off[c] = tab.dt_off[c] + 1u;  // skip the DTable header word
   }
   __syncthreads();
+  if (lane != 0) return;
 
-  // Lane 0 walks the chain; its output bytes go to an LDS line buffer that the whole wave
-  // copies out (coalesced) after every piece of at most DEC_LINE symbols: a byte store in the
-  // walking loop would sit in front of the next DTable load in the in-order vmcnt queue.
   BitReader br;
   br.w = w;
   br.pos = p0 - (long long)sum_logs;
-  if (lane == 0) br.refill();
+  br.refill();
   const uint32_t *__restrict__ dt = tab.dt;
-  long long pos_after = 0;
   for (unsigned r = j.n_recs; r > 0; r--) {  // records last -> first
     const fqgpu_rec rec = j.recs[r - 1];
-    uint8_t *out = j.raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off);
-    unsigned ctx = M::STREAM == 0 ? 0xD7u : (1u << 12);  // INITIAL_CONTEXT / calcContext(0,0,0)
-    unsigned q1 = 0, q2 = 0;
-    for (unsigned base = 0; base < rec.len; base += DEC_LINE) {
-      const unsigned n = min(DEC_LINE, rec.len - base);
-      if (lane == 0) {
-        for (unsigned i = 0; i < n; i++) {
-          const uint32_t e = dt[dt_off[ctx] + state[ctx]];
-          if (M::STREAM == 0) {
-            const unsigned sym = (e >> 16) & 3u;
-            state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
-            line[i] = (uint8_t)(0x54474341u >> (8u * sym));  // "ACGT"[sym]
-            ctx = (ctx >> 2) + (sym << 6);                   // addSymUpper
-          } else {
-            const unsigned q = (e >> 16) & 63u;
-            state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
-            line[i] = (uint8_t)(q + 33u);
-            ctx = fq_qual_ctx(q, q1, q2);
-            q2 = q1;
-            q1 = q;
-          }
-        }
+    if (M::STREAM == 0) {
+      uint8_t *out = j.raw + rec.seq_off;
+      unsigned ctx = 0xD7u;  // FSE_Sequence::INITIAL_CONTEXT
+      for (unsigned i = 0; i < rec.len; i++) {
+        const uint32_t e = dt[dt_off[ctx] + state[ctx]];
+        const unsigned sym = (e >> 16) & 3u;
+        state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
+        out[i] = (uint8_t)(0x54474341u >> (8u * sym));  // "ACGT"[sym]
+        ctx = (ctx >> 2) + (sym << 6);                   // addSymUpper
       }
-      fq_lds_wave_sync();
-      for (unsigned i = lane; i < n; i += 64) out[base + i] = line[i];
-      fq_lds_wave_sync();
+    } else {
+      uint8_t *out = j.raw + rec.qual_off;
+      unsigned ctx = 1u << 12, q1 = 0, q2 = 0;  // calcContext(0,0,0)
+      for (unsigned i = 0; i < rec.len; i++) {
+        const uint32_t e = dt[dt_off[ctx] + state[ctx]];
+        const unsigned q = (e >> 16) & 63u;
+        state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
+        out[i] = (uint8_t)(q + 33u);
+        ctx = fq_qual_ctx(q, q1, q2);
+        q2 = q1;
+        q1 = q;
+      }
     }
-    pos_after = __shfl(br.pos, 0);
-    if (pos_after < 0) break;
+    if (br.pos < 0) break;
   }
-  if (lane != 0) return;
   // BIT_endOfDStream (src/fse_common.hpp:141): every bit consumed, none invented
   if (br.pos != 0) res->corrupt = 1;
   res->total_bits = (unsigned long long)(p0 - (long long)sum_logs);
@@ -141,9 +130,8 @@ __global__ void __launch_bounds__(64)
 k_decode(const DecJob *__restrict__ jobs, unsigned n_blocks, TabView seq_tab, TabView qual_tab) {
   __shared__ uint16_t state[QualModel::B];
   __shared__ uint32_t dt_off[QualModel::B];
-  __shared__ uint8_t line[DEC_LINE];
-  if (blockIdx.x < n_blocks) decode_stream<QualModel>(jobs[blockIdx.x], qual_tab, state, dt_off, line);
-  else decode_stream<SeqModel>(jobs[blockIdx.x - n_blocks], seq_tab, state, dt_off, line);
+  if (blockIdx.x < n_blocks) decode_stream<QualModel>(jobs[blockIdx.x], qual_tab, state, dt_off);
+  else decode_stream<SeqModel>(jobs[blockIdx.x - n_blocks], seq_tab, state, dt_off);
 }
 
 // batch-wide record arrays: N counts widened for the scan
