@@ -25,6 +25,14 @@ struct DecJob {
   unsigned rec_base;  // first index of this block in the batch-wide record arrays
 };
 
+// Pointers read out of the job descriptors are generic to the compiler, which then emits
+// flat_load / flat_store: those also count on lgkmcnt, so every LDS wait of the walking loop
+// would wait for the previous output byte to reach memory.  Declare them global.
+#define FQ_GLOBAL __attribute__((address_space(1)))
+typedef FQ_GLOBAL uint8_t g_u8;
+typedef const FQ_GLOBAL uint32_t g_cu32;
+typedef const FQ_GLOBAL fqgpu_rec g_crec;
+
 struct TabView {
   const uint32_t *logs, *log_prefix, *dt, *dt_off;
 };
@@ -34,7 +42,7 @@ struct TabView {
 // little-endian bit array, bit pos-1 being the MSB.  A 64-bit register window is refilled
 // from two aligned dwords only when the read position leaves it.
 struct BitReader {
-  const uint32_t *w;   // stream as aligned dwords (buffers are padded)
+  g_cu32 *w;           // stream as aligned dwords (buffers are padded)
   long long pos;
   long long wbase;     // bit index of window bit 0 (multiple of 32)
   unsigned long long win;
@@ -55,7 +63,7 @@ struct BitReader {
 };
 
 // bits [lo, lo+nb) of the stream, for the data-parallel state load
-__device__ __forceinline__ unsigned peek_bits(const uint32_t *w, long long lo, unsigned nb) {
+__device__ __forceinline__ unsigned peek_bits(g_cu32 *w, long long lo, unsigned nb) {
   const unsigned wi = (unsigned)(lo >> 5);
   const unsigned long long v = (unsigned long long)w[wi] | ((unsigned long long)w[wi + 1] << 32);
   return (unsigned)(v >> (unsigned)(lo & 31)) & ((1u << nb) - 1u);
@@ -68,7 +76,9 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *sta
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
   StreamResult *res = &j.res->s[M::STREAM];
   const unsigned lane = threadIdx.x;
-  const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
+  g_cu32 *w = (g_cu32 *)reinterpret_cast<const uint32_t *>(src);
+  g_crec *recs = (g_crec *)j.recs;
+  g_u8 *raw = (g_u8 *)j.raw;
 
   // BIT_initDStream: the highest set bit of the last byte is the end mark
   const unsigned last = len ? src[len - 1] : 0u;
@@ -93,9 +103,10 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *sta
   br.refill();
   const uint32_t *__restrict__ dt = tab.dt;
   for (unsigned r = j.n_recs; r > 0; r--) {  // records last -> first
-    const fqgpu_rec rec = j.recs[r - 1];
+    fqgpu_rec rec;
+    rec.seq_off = recs[r - 1].seq_off; rec.qual_off = recs[r - 1].qual_off; rec.len = recs[r - 1].len;
     if (M::STREAM == 0) {
-      uint8_t *out = j.raw + rec.seq_off;
+      g_u8 *out = raw + rec.seq_off;
       unsigned ctx = 0xD7u;  // FSE_Sequence::INITIAL_CONTEXT
       for (unsigned i = 0; i < rec.len; i++) {
         const uint32_t e = dt[dt_off[ctx] + state[ctx]];
@@ -105,7 +116,7 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *sta
         ctx = (ctx >> 2) + (sym << 6);                   // addSymUpper
       }
     } else {
-      uint8_t *out = j.raw + rec.qual_off;
+      g_u8 *out = raw + rec.qual_off;
       unsigned ctx = 1u << 12, q1 = 0, q2 = 0;  // calcContext(0,0,0)
       for (unsigned i = 0; i < rec.len; i++) {
         const uint32_t e = dt[dt_off[ctx] + state[ctx]];
