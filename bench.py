@@ -92,6 +92,10 @@ def cpu_baseline(blocks, sft, qft, seconds_budget=20.0):
                       "per thread, best of <=3" % (threads, end / 2**20)}
 
 
+def ctx_lanes(args):
+    return max(1, min(8, args.lanes))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,11 +267,17 @@ def main():
     # and per-call buffers, and the GPU record parser against the host parser
     if rank == 0 and not args.skip_decode:
         raw0, recs0 = blocks[0]
-        t0 = time.perf_counter()
-        got = ctx.encode_block(raw0, recs0)
-        dt = time.perf_counter() - t0
-        assert got["rc"] == 0
-        extra["host_pointer_encode_MBps"] = round(raw0.size / dt / MB, 1)
+        raw0 = np.array(raw0, dtype=np.uint8, copy=True)
+        bufs = ctx.host_buffers(len(recs0), int(recs0["len"].sum()))
+        best = None
+        for _ in range(1 + ctx_lanes(args)):  # first calls grow the handle's staging block and lane scratch
+            t0 = time.perf_counter()
+            got = ctx.encode_block_into(raw0, recs0, bufs)
+            dt = time.perf_counter() - t0
+            assert got[0] == 0
+            best = dt if best is None else min(best, dt)
+        # one worker thread, pageable host memory, H2D + encode + D2H of streams and side streams
+        extra["host_pointer_encode_MBps"] = round(raw0.size / best / MB, 1)
         t0 = time.perf_counter()
         hr = F.parse_fastq(raw0)
         t_host = time.perf_counter() - t0

@@ -309,25 +309,32 @@ class Context:
         arr = (C.c_void_p * len(blocks))(*[b.h for b in blocks])
         _check(lib().fqgpu_dblocks_decode(self.h, arr, len(blocks)), "dblocks_decode")
 
+    @staticmethod
+    def host_buffers(n_recs, n_bases, seq_cap=None, qual_cap=None):
+        """Output buffers a worker keeps across chunks (the reference reuses its CompressedBuffersDst)."""
+        return dict(seq=np.zeros(bound_seq(n_bases) if seq_cap is None else seq_cap, dtype=np.uint8),
+                    qual=np.zeros(bound_qual(n_bases) if qual_cap is None else qual_cap, dtype=np.uint8),
+                    readlens=np.zeros(n_recs, dtype=np.uint16), n_count=np.zeros(n_recs, dtype=np.uint16),
+                    n_pos=np.zeros(n_bases + 1, dtype=np.uint16))
+
+    def encode_block_into(self, raw, recs, bufs, flags=0):
+        """fqgpu_encode_block on the caller's arrays, nothing copied or allocated on the Python side.
+        raw is written to when flags has F_WRITE_BACK_N.  -> (rc, seq_len, qual_len, n_pos_len)"""
+        sl, ql, nn = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        rc = lib().fqgpu_encode_block(self.h, _p(raw), raw.size, _p(recs), len(recs), _p(bufs["seq"]),
+                                      bufs["seq"].size, C.byref(sl), _p(bufs["qual"]), bufs["qual"].size,
+                                      C.byref(ql), _p(bufs["readlens"]), _p(bufs["n_count"]), _p(bufs["n_pos"]),
+                                      bufs["n_pos"].size, C.byref(nn), flags)
+        return rc, sl.value, ql.value, nn.value
+
     def encode_block(self, raw, recs, flags=0, seq_cap=None, qual_cap=None):
         """Host-pointer call (fqgpu_encode_block) -> dict like the oracle's."""
         raw = np.array(raw, dtype=np.uint8, copy=True)
         recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
-        n = len(recs)
-        bases = int(recs["len"].sum())
-        seq_cap = bound_seq(bases) if seq_cap is None else seq_cap
-        qual_cap = bound_qual(bases) if qual_cap is None else qual_cap
-        seq = np.zeros(seq_cap, dtype=np.uint8)
-        qual = np.zeros(qual_cap, dtype=np.uint8)
-        rl = np.zeros(n, dtype=np.uint16)
-        nc = np.zeros(n, dtype=np.uint16)
-        npos = np.zeros(bases + 1, dtype=np.uint16)
-        sl, ql, nn = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
-        rc = lib().fqgpu_encode_block(self.h, _p(raw), raw.size, _p(recs), n, _p(seq), seq_cap, C.byref(sl),
-                                      _p(qual), qual_cap, C.byref(ql), _p(rl), _p(nc), _p(npos), npos.size,
-                                      C.byref(nn), flags)
-        return dict(rc=rc, seq=seq[: sl.value].copy(), qual=qual[: ql.value].copy(), readlens=rl, n_count=nc,
-                    n_pos=npos[: nn.value].copy(), raw_after=raw)
+        bufs = self.host_buffers(len(recs), int(recs["len"].sum()), seq_cap, qual_cap)
+        rc, sl, ql, nn = self.encode_block_into(raw, recs, bufs, flags)
+        return dict(rc=rc, seq=bufs["seq"][:sl].copy(), qual=bufs["qual"][:ql].copy(), readlens=bufs["readlens"],
+                    n_count=bufs["n_count"], n_pos=bufs["n_pos"][:nn].copy(), raw_after=raw)
 
     def decode_block(self, seq, qual, n_count, n_pos, recs, raw_skeleton):
         out = np.array(raw_skeleton, dtype=np.uint8, copy=True)

@@ -353,6 +353,7 @@ extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
   DevBuf *bufs[] = {&ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < FQ_MAX_LANES; i++) free_lane(ctx->lanes[i]);
+  if (ctx->hp_block) fqgpu_dblock_destroy(ctx->hp_block);
   if (ctx->timer) {
     for (hipEvent_t e : ctx->timer->pool) (void)hipEventDestroy(e);
     delete ctx->timer;
@@ -645,39 +646,78 @@ extern "C" int fqgpu_dblocks_decode(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks,
 }
 
 // ------------------------------------------------------------------ host-pointer convenience calls
+// The two calls below stage through one device block the handle keeps between calls: a worker
+// that codes chunk after chunk (reference src/process.cpp:49-54) pays hipMalloc only while its
+// chunks are still growing.
+template <class T>
+static bool hp_grow(T *&p, size_t &have, size_t need) {
+  if (p && need <= have) return true;
+  if (p) (void)hipFree(p);
+  have = need + need / 8;
+  p = fq_dev_alloc<T>(have);
+  if (!p) have = 0;
+  return p != nullptr;
+}
+
+static int hp_block_acquire(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_t n_bases, size_t seq_cap,
+                            size_t qual_cap, size_t n_pos_cap, fqgpu_dblock **out) {
+  fqgpu_dblock *b = ctx->hp_block;
+  if (!b) {
+    b = ctx->hp_block = new (std::nothrow) fqgpu_dblock();
+    if (!b) return FQGPU_E_NOMEM;
+    b->device = ctx->device;
+    b->result = fq_dev_alloc<BlockResult>(1);
+    if (!b->result) return FQGPU_E_NOMEM;
+  }
+  size_t side2 = ctx->hp_side;
+  const bool ok = hp_grow(b->raw, ctx->hp_raw, raw_len + 64) && hp_grow(b->recs, ctx->hp_recs, n_recs) &&
+                  hp_grow(b->seq, ctx->hp_seq, seq_cap + 64) && hp_grow(b->qual, ctx->hp_qual, qual_cap + 64) &&
+                  hp_grow(b->readlens, ctx->hp_side, n_recs) && hp_grow(b->n_count, side2, n_recs) &&
+                  hp_grow(b->n_pos, ctx->hp_npos, n_pos_cap + 16);
+  if (!ok) {  // leave nothing half-sized behind
+    fqgpu_dblock_destroy(b);
+    ctx->hp_block = nullptr;
+    ctx->hp_raw = ctx->hp_recs = ctx->hp_seq = ctx->hp_qual = ctx->hp_side = ctx->hp_npos = 0;
+    return FQGPU_E_NOMEM;
+  }
+  b->raw_len = raw_len; b->n_recs = n_recs; b->n_bases = n_bases;
+  b->seq_cap = seq_cap; b->qual_cap = qual_cap; b->n_pos_cap = n_pos_cap;
+  b->seq_len = b->qual_len = b->n_pos_len = 0;
+  b->last_op = 0;
+  memset(&b->host_result, 0, sizeof(b->host_result));
+  *out = b;
+  return FQGPU_OK;
+}
+
 extern "C" int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
                                   size_t n_recs, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
                                   uint8_t *qual_out, size_t qual_cap, size_t *qual_len,
                                   uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
                                   size_t n_pos_cap, size_t *n_pos_len, unsigned flags) {
-  if (!ctx || !seq_out || !qual_out || !seq_len || !qual_len) return FQGPU_E_ARG;
-  fqgpu_dblock *b = nullptr;
-  int rc = fqgpu_dblock_create(ctx, raw, raw_len, recs, n_recs, &b);
+  if (!ctx || !raw || !recs || !n_recs || !seq_out || !qual_out || !seq_len || !qual_len) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
   if (rc) return rc;
-  // the caller's capacities are the ones the overflow rule is judged against
-  if (seq_cap > b->seq_cap) {
-    (void)hipFree(b->seq);
-    b->seq = fq_dev_alloc<uint8_t>(seq_cap + 64);
-  }
-  if (qual_cap > b->qual_cap) {
-    (void)hipFree(b->qual);
-    b->qual = fq_dev_alloc<uint8_t>(qual_cap + 64);
-  }
-  if (!b->seq || !b->qual) { fqgpu_dblock_destroy(b); return FQGPU_E_NOMEM; }
-  b->seq_cap = seq_cap;
-  b->qual_cap = qual_cap;
-  do {
-    if ((rc = fq_encode_launch(ctx, b, flags))) break;
-    if ((rc = fqgpu_sync(ctx))) break;
-    if ((rc = pull_result(b, true))) break;
-    if (n_pos_out && b->n_pos_len > n_pos_cap) { rc = FQGPU_E_ARG; break; }
-    rc = fqgpu_dblock_fetch(ctx, b, seq_out, qual_out, readlens_out, n_count_out, n_pos_out,
-                            (flags & FQGPU_F_WRITE_BACK_N) ? raw : nullptr);
-    *seq_len = b->seq_len;
-    *qual_len = b->qual_len;
-    if (n_pos_len) *n_pos_len = b->n_pos_len;
-  } while (0);
-  fqgpu_dblock_destroy(b);
+  size_t n_bases = 0;
+  if ((rc = check_recs(recs, n_recs, raw_len, &n_bases))) return rc;
+  if ((rc = fqgpu_sync(ctx))) return rc;
+  // The caller's capacities are the ones the overflow rule is judged against.  n_pos is sized
+  // for the worst case (every base an N) instead of pre-counting the N's on the host.
+  fqgpu_dblock *b = nullptr;
+  if ((rc = hp_block_acquire(ctx, raw_len, n_recs, n_bases, seq_cap, qual_cap, n_bases, &b))) return rc;
+  FQ_HIP(hipMemcpyAsync(b->raw, raw, raw_len, hipMemcpyHostToDevice, ctx->stream));
+  FQ_HIP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, ctx->stream));
+  FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), ctx->stream));
+  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  b->last_op = 1;
+  if ((rc = fq_encode_launch(ctx, b, flags))) return rc;
+  if ((rc = fqgpu_sync(ctx))) return rc;
+  if ((rc = pull_result(b, true))) return rc;
+  if (n_pos_out && b->n_pos_len > n_pos_cap) return FQGPU_E_ARG;
+  rc = fqgpu_dblock_fetch(ctx, b, seq_out, qual_out, readlens_out, n_count_out, n_pos_out,
+                          (flags & FQGPU_F_WRITE_BACK_N) ? raw : nullptr);
+  *seq_len = b->seq_len;
+  *qual_len = b->qual_len;
+  if (n_pos_len) *n_pos_len = b->n_pos_len;
   return rc;
 }
 
@@ -687,19 +727,27 @@ extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq
                                   size_t n_recs, uint8_t *raw_out, size_t raw_len) {
   if (!ctx || !seq || !qual || !n_count || !recs || !raw_out || !seq_len || !qual_len) return FQGPU_E_ARG;
   if (n_count_len < n_recs) return FQGPU_E_CORRUPT;
-  fqgpu_dblock *b = nullptr;
-  int rc = fqgpu_dblock_create(ctx, raw_out, raw_len, recs, n_recs, &b);
+  int rc = use_device(ctx->device);
   if (rc) return rc;
-  do {
-    // the reference pops from the END of n_count (src/fse_sequence.cpp:115-126)
-    if ((rc = fqgpu_dblock_load_streams(ctx, b, seq, seq_len, qual, qual_len, n_count + (n_count_len - n_recs),
-                                        n_pos, n_pos_len))) break;
-    fqgpu_dblock *one[1] = {b};
-    if ((rc = fq_decode_launch(ctx, one, 1))) break;
-    if ((rc = fqgpu_sync(ctx))) break;
-    if ((rc = pull_result(b, false))) break;
-    rc = fqgpu_dblock_fetch(ctx, b, nullptr, nullptr, nullptr, nullptr, nullptr, raw_out);
-  } while (0);
-  fqgpu_dblock_destroy(b);
-  return rc;
+  size_t n_bases = 0;
+  if ((rc = check_recs(recs, n_recs, raw_len, &n_bases))) return rc;
+  if ((rc = fqgpu_sync(ctx))) return rc;
+  fqgpu_dblock *b = nullptr;
+  const size_t seq_cap = seq_len > fqgpu_bound_seq(n_bases) ? seq_len : fqgpu_bound_seq(n_bases);
+  const size_t qual_cap = qual_len > fqgpu_bound_qual(n_bases) ? qual_len : fqgpu_bound_qual(n_bases);
+  if ((rc = hp_block_acquire(ctx, raw_len, n_recs, n_bases, seq_cap, qual_cap, n_pos_len, &b))) return rc;
+  // raw_out holds the skeleton the first decode pass laid out (headers, newlines, '+')
+  FQ_HIP(hipMemcpyAsync(b->raw, raw_out, raw_len, hipMemcpyHostToDevice, ctx->stream));
+  FQ_HIP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, ctx->stream));
+  FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), ctx->stream));
+  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  // the reference pops from the END of n_count (src/fse_sequence.cpp:115-126)
+  if ((rc = fqgpu_dblock_load_streams(ctx, b, seq, seq_len, qual, qual_len, n_count + (n_count_len - n_recs),
+                                      n_pos, n_pos_len))) return rc;
+  b->last_op = 2;
+  fqgpu_dblock *one[1] = {b};
+  if ((rc = fq_decode_launch(ctx, one, 1))) return rc;
+  if ((rc = fqgpu_sync(ctx))) return rc;
+  if ((rc = pull_result(b, false))) return rc;
+  return fqgpu_dblock_fetch(ctx, b, nullptr, nullptr, nullptr, nullptr, nullptr, raw_out);
 }

@@ -135,6 +135,9 @@ struct fqgpu_ctx {
   DevBuf n_cnt32, n_off, scan_tmp;
   DevBuf dec_desc;    // decode job descriptors
   KernelTimer *timer = nullptr;
+  // staging block of the host-pointer calls, kept between calls (grow-only device buffers)
+  fqgpu_dblock *hp_block = nullptr;
+  size_t hp_raw = 0, hp_recs = 0, hp_seq = 0, hp_qual = 0, hp_side = 0, hp_npos = 0;  // allocated elements
 };
 
 EncLane *fq_next_lane(fqgpu_ctx *ctx);  // api.hip: round-robin, creates streams on first use
