@@ -107,9 +107,9 @@ def main():
     ap.add_argument("--decode-block-mib", type=int, default=1, help="block size of the many-blocks decode run")
     ap.add_argument("--decode-mib", type=int, default=256, help="data decoded in the many-blocks run")
     ap.add_argument("--lanes", type=int, default=4, help="blocks in flight per GPU (encode lanes)")
-    ap.add_argument("--seq-mode", default="two", choices=["two", "one", "generic"],
-                    help="sequence chain kernels: two symbols per step (default), one, reset-cut kernel")
-    ap.add_argument("--seq-part", type=int, default=None, help="part length of split sequence chains (symbols)")
+    ap.add_argument("--seq-mode", default="sets", choices=["sets", "generic"],
+                    help="sequence chain kernels: segment functions over state sets (default), reset-cut kernel")
+    ap.add_argument("--seq-segment", type=int, default=None, help="segment length of the sequence chain kernels")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank); gloo only to rehearse the "
                     "multi-rank path on a one-GPU box (all ranks then share GPU 0)")
     ap.add_argument("--skip-decode", action="store_true")
@@ -143,8 +143,7 @@ def main():
     sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
     ctx = F.Context(sft, qft, device=device)
     ctx.set_lanes(max(1, min(args.lanes, 8)))
-    ctx.set_chain_params(0, seq_generic=args.seq_mode == "generic", seq_one_symbol=args.seq_mode == "one",
-                         seq_part_target=args.seq_part)
+    ctx.set_chain_params(0, seq_generic=args.seq_mode == "generic", seq_segment=args.seq_segment)
     dblocks = [ctx.dblock(raw, recs) for raw, recs in blocks]
     raw_bytes = sum(raw.size for raw, _ in blocks)
     n_recs = sum(len(r) for _, r in blocks)

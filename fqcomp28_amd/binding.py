@@ -86,7 +86,7 @@ _PROTOS = {
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fqgpu_dblock_longest_chain": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "fqgpu_ctx_set_lanes": (C.c_int, [C.c_void_p, C.c_uint]),
-    "fqgpu_ctx_set_seq_part_target": (C.c_int, [C.c_void_p, C.c_uint]),
+    "fqgpu_ctx_set_seq_segment": (C.c_int, [C.c_void_p, C.c_uint]),
     "fqgpu_dblock_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "fqgpu_dblock_load_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -272,10 +272,10 @@ class Context:
 
     __del__ = close
 
-    def set_chain_params(self, segment=0, seq_generic=False, seq_one_symbol=False, seq_part_target=None):
-        flags = (1 if seq_generic else 0) | (2 if seq_one_symbol else 0)
-        if seq_part_target is not None:
-            _check(lib().fqgpu_ctx_set_seq_part_target(self.h, seq_part_target), "set_seq_part_target")
+    def set_chain_params(self, segment=0, seq_generic=False, seq_segment=None):
+        flags = 1 if seq_generic else 0
+        if seq_segment is not None:
+            _check(lib().fqgpu_ctx_set_seq_segment(self.h, seq_segment), "set_seq_segment")
         _check(lib().fqgpu_ctx_set_chain_params(self.h, segment, flags), "set_chain_params")
 
     def set_lanes(self, lanes):

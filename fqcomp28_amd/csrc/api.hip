@@ -290,7 +290,7 @@ extern "C" int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len,
 
 // ------------------------------------------------------------------ handle
 static void free_tables(DevTables &t) {
-  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off};
+  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off, t.next1};
   for (void *p : ps) if (p) (void)hipFree(p);
   t = DevTables();
 }
@@ -369,13 +369,12 @@ extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsi
     ctx->seg_len = segment;
   }
   ctx->seq_generic = (flags & FQGPU_CHAIN_SEQ_GENERIC) ? 1 : 0;
-  ctx->seq_one_symbol = (flags & FQGPU_CHAIN_SEQ_ONE_SYMBOL) ? 1 : 0;
   return FQGPU_OK;
 }
 
-extern "C" int fqgpu_ctx_set_seq_part_target(fqgpu_ctx *ctx, unsigned symbols) {
+extern "C" int fqgpu_ctx_set_seq_segment(fqgpu_ctx *ctx, unsigned symbols) {
   if (!ctx) return FQGPU_E_ARG;
-  ctx->seq_part_target = symbols;
+  ctx->seq_segment = symbols;
   return FQGPU_OK;
 }
 

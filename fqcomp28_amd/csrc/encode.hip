@@ -40,8 +40,6 @@ constexpr unsigned PACK_TILE = 4096;   // symbols per bit-packing tile
 constexpr unsigned PACK_THREADS = 256;
 constexpr unsigned PACK_PER_THREAD = PACK_TILE / PACK_THREADS;  // 16
 constexpr unsigned CTX_PAD = 16;       // every context's sorted run starts 16-aligned
-constexpr unsigned FQ_MAX_LOG_SEQ = 12;  // FSE_MAX_TABLELOG: slot size of a composed function
-constexpr unsigned FQ_MAX_LOG_T2 = 11;   // two-symbol table only up to this log (64 KB)
 
 template <class M> constexpr unsigned tile_size() { return M::STREAM == 0 ? TILE_SEQ : TILE_QUAL; }
 
@@ -501,349 +499,338 @@ k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ ou
 }
 
 // ---- sequence chains -------------------------------------------------------------------
-// Sequence contexts have no single-state symbols, so a chain cannot be cut "for free".  Two
-// exact tools are used instead:
-//  (1) the per-step latency: the transition table is expanded in LDS so that a step is one add
-//      and one 2-byte LDS read (62.5 shader cycles = 26 ns, tools/chain_ubench.hip), two symbols
-//      per step through T2[s2][s1][x] (64 KB at log 11);
-//  (2) function composition: the effect of a chunk of symbols on the state is a function
-//      F: {0..size-1} -> {0..size-1}.  k_seq_compose computes F for every 4096-symbol chunk of
-//      the leading parts of a LONG chain by walking all `size` states through the chunk (256
-//      lanes x 8 states, LDS-throughput-bound, all chunks in parallel); k_seq_apply chains the
-//      F's (one lookup per chunk) and so obtains the exact start state of every part.  Long
-//      chains (context 0xD7 also receives the first base of every read: 2.7x the average) are
-//      thereby split into parts of about the average chain length that are walked concurrently.
-constexpr unsigned COMPOSE_CHUNK = 4096;  // symbols per composed function; parts are multiples of it
+// Sequence contexts have no single-state symbols, so a chain cannot be cut "for free", and a
+// tANS encoder state never forgets its history.  But it forgets MOST of it: pushed through the
+// same symbols, the 2^log possible states collapse onto a small set (about 150 survivors
+// after 128 symbols for exactly uniform counts, a few dozen otherwise), because every
+// transition x -> stateTable[(x >> nb) + delta] merges the states that share x >> nb.  The
+// chain of a context is therefore cut into segments of S symbols and coded in three exact steps:
+//  (A) k_seq_setfunc: one wave per segment computes F: entry state -> exit state for EVERY
+//      possible entry state.  It starts with all 2^log states spread over the lanes, and at a
+//      few points (after 4, 16, 48, 128, 512, 2048, ... symbols) replaces the states it carries by
+//      the distinct ones ("classes"), remembering which class every entry state fell into.
+//      After the first hundred symbols a step costs 1-3 LDS gathers per wave for 64 lanes.
+//  (B) k_seq_resolve: entry state of every segment, x <- F_k[x] segment after segment.
+//  (C) k_seq_emit: every lane walks ONE segment from its now-known entry state and writes the
+//      packed (nb, bits) of every symbol; 64 segments of a context per wave.
+// All three read the context's one-symbol transition table next[s][x] from LDS (tables.hip
+// builds it once per handle).  Exact by construction: no speculation, nothing to verify.
+constexpr unsigned SETS_WAVES = 8;          // segments (waves) per workgroup in step A
+constexpr unsigned SETS_MAX_CLASSES = 512;  // above this a segment keeps carrying every state
+constexpr unsigned SETS_BLOCK = 1024;       // symbols per 16-byte-per-lane load; S is a multiple
 
-struct SeqPart {
-  uint32_t ctx, begin, len;  // symbols [begin, begin + len) of the context's run
-  uint32_t start_xo;         // (state - size) * 2 in front of symbol `begin`
-  uint32_t last;             // this part ends the chain: it owns final_state[ctx]
+struct SetsWaveLds {
+  uint32_t bm[128];                  // bitmap over the states (size <= 4096)
+  uint16_t wpre[128];                // set bits before every bitmap word
+  uint16_t list[SETS_MAX_CLASSES];   // class -> state, as (state - size) * 2
+  uint16_t tmp[SETS_MAX_CLASSES];    // old class -> new class during a merge
+  uint16_t m[SETS_MAX_CLASSES];      // first-level class -> current class
 };
 
-// plan[]: n_parts | n_compose_chunks | cprefix[B + 1] (compose chunks before every context)
-//         | eprefix[B + 1] (parts before every context) | cpp[B] (compose chunks per part)
-constexpr unsigned PLAN_WORDS = 2 + 3 * SeqModel::B + 2;
+// plan[]: fitem_base[B+1] (step A workgroups before every context) | fseg_base[B+1] (functions
+// before every context) | seg_base[B+1] (segments) | eitem_base[B+1] (step C waves)
+constexpr unsigned SEGPLAN_WORDS = 4 * (SeqModel::B + 1);
 
 __global__ void __launch_bounds__(256)
-k_seq_plan(const uint32_t *__restrict__ arrays, unsigned n_sym, unsigned target, uint32_t *__restrict__ plan,
-           SeqPart *__restrict__ parts) {
+k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, uint32_t *__restrict__ plan) {
   constexpr unsigned B = SeqModel::B;
-  __shared__ unsigned s_comp[B], s_parts[B];
+  __shared__ unsigned s_nseg[B];
   const unsigned c = threadIdx.x;
   const unsigned n = arrays[c];
-  // target part length: the average chain of this block (at least one compose chunk)
-  unsigned L = target ? target : max(n_sym / B, COMPOSE_CHUNK);
-  L = ((L + COMPOSE_CHUNK - 1) / COMPOSE_CHUNK) * COMPOSE_CHUNK;
-  unsigned P = 1, plen = n;
-  if (n > L + L / 8) {  // worth splitting: more than 12.5 % above the target
-    P = (n + L - 1) / L;
-    plen = (((n + P - 1) / P + COMPOSE_CHUNK - 1) / COMPOSE_CHUNK) * COMPOSE_CHUNK;
-    P = (n + plen - 1) / plen;
-  }
-  if (n == 0) P = 0;
-  const unsigned cpp = P > 1 ? plen / COMPOSE_CHUNK : 0;
-  s_parts[c] = P;
-  s_comp[c] = P > 1 ? (P - 1) * cpp : 0;
+  s_nseg[c] = (n + S - 1) / S;
   __syncthreads();
-  unsigned ep = 0, cp = 0;
-  for (unsigned o = 0; o < c; o++) { ep += s_parts[o]; cp += s_comp[o]; }
-  uint32_t *cprefix = plan + 2, *eprefix = cprefix + B + 1, *cpps = eprefix + B + 1;
-  cprefix[c] = cp; eprefix[c] = ep; cpps[c] = cpp;
+  unsigned fi = 0, fs = 0, sg = 0, ei = 0;
+  for (unsigned o = 0; o < c; o++) {
+    const unsigned ns = s_nseg[o], nf = ns ? ns - 1 : 0;
+    fi += (nf + SETS_WAVES - 1) / SETS_WAVES; fs += nf; sg += ns; ei += (ns + 63) / 64;
+  }
+  uint32_t *fitem = plan, *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *eitem = plan + 3 * (B + 1);
+  fitem[c] = fi; fseg[c] = fs; seg[c] = sg; eitem[c] = ei;
   if (c == B - 1) {
-    cprefix[B] = cp + s_comp[c]; eprefix[B] = ep + s_parts[c];
-    plan[0] = ep + s_parts[c]; plan[1] = cp + s_comp[c];
-  }
-  for (unsigned p = 0; p < P; p++) {
-    SeqPart q;
-    q.ctx = c; q.begin = p * plen; q.len = min(plen, n - p * plen);
-    q.start_xo = 0; q.last = (p == P - 1);
-    parts[ep + p] = q;
+    const unsigned ns = s_nseg[c], nf = ns ? ns - 1 : 0;
+    fitem[B] = fi + (nf + SETS_WAVES - 1) / SETS_WAVES; fseg[B] = fs + nf; seg[B] = sg + ns; eitem[B] = ei + (ns + 63) / 64;
   }
 }
 
-// one-symbol transition table of a context in LDS: next[s][x - size] = (state after s) - size,
-// pre-scaled to the byte offset of the following lookup
-__device__ __forceinline__ void build_next1(uint16_t *next, const uint32_t *__restrict__ tbl, unsigned log,
-                                            unsigned nthreads) {
-  const unsigned size = 1u << log;
-  const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
-  const uint32_t *tt = tbl + 1 + (size >> 1);
-  for (unsigned e = threadIdx.x; e < 4 * size; e += nthreads) {
-    const unsigned s = e >> log, xi = e & (size - 1), x = size + xi;
-    const unsigned nb = (x + tt[2 * s + 1]) >> 16;
-    next[e] = (uint16_t)(((unsigned)st[(int)(x >> nb) + (int)tt[2 * s]] - size) * 2u);
-  }
-}
-
-// F of one chunk: all `size` states walked through its COMPOSE_CHUNK symbols.
-// One workgroup of 256 threads per chunk, up to 16 states per thread (size <= 4096).
-__global__ void __launch_bounds__(256)
-k_seq_compose(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
-              const uint32_t *__restrict__ plan, const uint32_t *__restrict__ ct,
-              const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ fbuf) {
-  extern __shared__ uint32_t lds[];
-  __shared__ uint4 symbuf[COMPOSE_CHUNK / 16];
-  constexpr unsigned B = SeqModel::B;
-  const unsigned g = blockIdx.x;
-  if (g >= plan[1]) return;  // the grid is an upper bound
-  const uint32_t *cprefix = plan + 2;
-  unsigned lo = 0, hi = B - 1;  // context owning compose chunk g
+// last context c with base[c] <= item (base is an exclusive prefix with B + 1 entries)
+__device__ __forceinline__ unsigned seq_item_ctx(const uint32_t *__restrict__ base, unsigned item) {
+  unsigned lo = 0, hi = SeqModel::B - 1;
   while (lo < hi) {
     const unsigned mid = lo + ((hi - lo + 1) >> 1);
-    if (cprefix[mid] <= g) lo = mid; else hi = mid - 1;
+    if (base[mid] <= item) lo = mid; else hi = mid - 1;
   }
-  const unsigned c = lo, j = g - cprefix[c];
-  const uint32_t *tbl = ct + ct_off[c];
-  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
-  uint16_t *next = reinterpret_cast<uint16_t *>(lds);
-  build_next1(next, tbl, log, 256);
-  const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)j * COMPOSE_CHUNK);
-  symbuf[threadIdx.x] = gsym[threadIdx.x];  // 256 threads x 16 symbols
+  return lo;
+}
+
+__device__ __forceinline__ unsigned sets_incl_scan(unsigned v) {
+  const unsigned lane = fq_lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(v, d);
+    if (lane >= (unsigned)d) v += o;
+  }
+  return v;
+}
+
+// The segment's symbols travel 1024 at a time: lane l holds symbols 16 l .. 16 l + 15 of the
+// block, a word of four symbols is fetched with v_readlane (w: uniform word index in the segment).
+__device__ __forceinline__ unsigned sets_word(const uint4 cur, unsigned w) {
+  const unsigned g = (w >> 2) & 63u, q = w & 3u;
+  const unsigned a = __builtin_amdgcn_readlane(cur.x, g), b = __builtin_amdgcn_readlane(cur.y, g),
+                 c = __builtin_amdgcn_readlane(cur.z, g), d = __builtin_amdgcn_readlane(cur.w, g);
+  return q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
+}
+
+// number of distinct states marked in L.bm; fills L.wpre
+__device__ __forceinline__ unsigned sets_count(SetsWaveLds &L, unsigned nw) {
+  const unsigned lane = fq_lane();
+  const unsigned c0 = lane < nw ? __popc(L.bm[lane]) : 0u, c1 = lane + 64 < nw ? __popc(L.bm[lane + 64]) : 0u;
+  const unsigned p0 = sets_incl_scan(c0), t0 = __builtin_amdgcn_readlane(p0, 63);
+  const unsigned p1 = sets_incl_scan(c1), t1 = __builtin_amdgcn_readlane(p1, 63);
+  L.wpre[lane] = (uint16_t)(p0 - c0);
+  L.wpre[lane + 64] = (uint16_t)(t0 + p1 - c1);
+  fq_lds_wave_sync();
+  return t0 + t1;
+}
+__device__ __forceinline__ unsigned sets_rank(const SetsWaveLds &L, unsigned xi) {
+  return (unsigned)L.wpre[xi >> 5] + __popc(L.bm[xi >> 5] & ((1u << (xi & 31u)) - 1u));
+}
+__device__ __forceinline__ void sets_clear(SetsWaveLds &L) {
+  L.bm[fq_lane()] = 0; L.bm[fq_lane() + 64] = 0;
+  fq_lds_wave_sync();
+}
+
+// n classes (states in L.list) walked through words [w0, w1) of the segment, M per lane
+template <int M>
+__device__ __forceinline__ void sets_walk(SetsWaveLds &L, unsigned n, const char *tbase, unsigned log,
+                                          const uint4 cur, unsigned w0, unsigned w1) {
+  const unsigned lane = fq_lane();
+  unsigned y[M];
+#pragma unroll
+  for (int j = 0; j < M; j++) {
+    const unsigned i = lane + 64u * j;
+    y[j] = L.list[i < n ? i : n - 1];  // spare slots shadow the last class
+  }
+  for (unsigned w = w0; w < w1; w++) {
+    const unsigned word = sets_word(cur, w);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const unsigned row = ((word >> (8 * i)) & 3u) << (log + 1);
+#pragma unroll
+      for (int j = 0; j < M; j++) y[j] = *reinterpret_cast<const uint16_t *>(tbase + (row + y[j]));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < M; j++) {
+    const unsigned i = lane + 64u * j;
+    if (i < n) L.list[i] = (uint16_t)y[j];
+  }
+  fq_lds_wave_sync();
+}
+
+// merge of equal states among the n classes of L.list; returns the new class count.  Skipped
+// (list untouched) when it would not lower the number of gathers per step.
+__device__ __forceinline__ unsigned sets_merge(SetsWaveLds &L, unsigned n, unsigned n1, unsigned nw) {
+  const unsigned lane = fq_lane();
+  sets_clear(L);
+  for (unsigned i = lane; i < n; i += 64) {
+    const unsigned xi = (unsigned)L.list[i] >> 1;
+    atomicOr(&L.bm[xi >> 5], 1u << (xi & 31u));
+  }
+  fq_lds_wave_sync();
+  const unsigned nn = sets_count(L, nw);
+  if ((nn + 63) / 64 >= (n + 63) / 64) return n;
+  unsigned st[SETS_MAX_CLASSES / 64];
+#pragma unroll
+  for (unsigned j = 0; j < SETS_MAX_CLASSES / 64; j++) {
+    const unsigned i = lane + 64u * j;
+    st[j] = i < n ? (unsigned)L.list[i] : 0u;
+    if (i < n) L.tmp[i] = (uint16_t)sets_rank(L, st[j] >> 1);
+  }
+  fq_lds_wave_sync();
+#pragma unroll
+  for (unsigned j = 0; j < SETS_MAX_CLASSES / 64; j++) {
+    const unsigned i = lane + 64u * j;
+    if (i < n) L.list[L.tmp[i]] = (uint16_t)st[j];  // equal states write the same value
+  }
+  for (unsigned i = lane; i < n1; i += 64) L.m[i] = L.tmp[L.m[i]];
+  fq_lds_wave_sync();
+  return nn;
+}
+
+// Step A.  PER0 = states per lane at the start: 32 covers log <= 11, 64 covers log 12.
+template <unsigned PER0>
+__global__ void __launch_bounds__(SETS_WAVES * 64)
+k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
+              const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs,
+              const uint16_t *__restrict__ next1, unsigned next_stride, unsigned S, unsigned fstride,
+              uint16_t *__restrict__ fbuf) {
+  extern __shared__ uint32_t lds[];  // next[4][size] of this context
+  __shared__ SetsWaveLds wl[SETS_WAVES];
+  constexpr unsigned B = SeqModel::B;
+  const uint32_t *fitem = plan, *fseg = plan + (B + 1);
+  if (blockIdx.x >= fitem[B]) return;  // the grid is an upper bound
+  const unsigned c = seq_item_ctx(fitem, blockIdx.x);
+  const unsigned log = logs[c], size = 1u << log;
+  {  // 4 * size u16 entries, a multiple of 16 bytes
+    const uint4 *src = reinterpret_cast<const uint4 *>(next1 + (size_t)c * next_stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (unsigned e = threadIdx.x; e < size / 2; e += SETS_WAVES * 64) dst[e] = src[e];
+  }
   __syncthreads();
-  const char *nbase = reinterpret_cast<const char *>(next);
-  const unsigned per = max(size >> 8, 1u);  // states per thread
-  unsigned x[16];
-#pragma unroll
-  for (unsigned k = 0; k < 16; k++) x[k] = ((threadIdx.x * per + k) & (size - 1)) * 2u;
-  for (unsigned v = 0; v < COMPOSE_CHUNK / 16; v++) {
-    const uint4 sv = symbuf[v];  // same address in every lane: LDS broadcast
-    const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const unsigned row = ((w[i >> 2] >> (8 * (i & 3))) & 3u) << (log + 1);
-#pragma unroll
-      for (unsigned k = 0; k < 16; k++)
-        if (k < per) x[k] = *reinterpret_cast<const uint16_t *>(nbase + (row + x[k]));
-    }
-  }
-  uint16_t *f = fbuf + (size_t)g * (1u << FQ_MAX_LOG_SEQ);
-#pragma unroll
-  for (unsigned k = 0; k < 16; k++)
-    if (k < per && threadIdx.x * per + k < size) f[threadIdx.x * per + k] = (uint16_t)x[k];
-}
-
-// start state of every part of every split chain: x <- F_chunk[x], chunk after chunk
-__global__ void __launch_bounds__(256)
-k_seq_apply(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, SeqPart *__restrict__ parts) {
-  constexpr unsigned B = SeqModel::B;
-  const unsigned c = threadIdx.x;
-  const uint32_t *cprefix = plan + 2, *eprefix = cprefix + B + 1, *cpps = eprefix + B + 1;
-  const unsigned n_comp = cprefix[c + 1] - cprefix[c], cpp = cpps[c];
-  if (n_comp == 0) return;
-  unsigned xo = 0;  // FSE_initCState: state = size
-  for (unsigned j = 0; j < n_comp; j++) {
-    xo = fbuf[(size_t)(cprefix[c] + j) * (1u << FQ_MAX_LOG_SEQ) + (xo >> 1)];
-    if ((j + 1) % cpp == 0) parts[eprefix[c] + (j + 1) / cpp].start_xo = xo;
-  }
-}
-
-// (state, symbol) -> (nb << 12 | low nb bits of the state) for 8 consecutive symbols of a
-// chunk; states come from statebuf (every symbol: STRIDE 1; every even symbol: STRIDE 2, the
-// odd ones are recomputed with one transition straight from the L1-resident CTable)
-template <int STRIDE>
-__device__ __forceinline__ uint4 seq_outputs8(const uint8_t *sbytes, const uint16_t *statebuf,
-                                              const uint16_t *__restrict__ st, const int *dfs, unsigned v,
-                                              unsigned size, const unsigned *dnb) {
-  unsigned o[4];
-#pragma unroll
-  for (int j = 0; j < 8; j += 2) {
-    const unsigned i = v * 8 + j;
-    const unsigned s1 = sbytes[i] & 3u, s2 = sbytes[i + 1] & 3u;
-    const unsigned x1 = size + ((unsigned)statebuf[STRIDE == 1 ? i : (i >> 1)] >> 1);
-    const unsigned d1 = s1 == 0 ? dnb[0] : s1 == 1 ? dnb[1] : s1 == 2 ? dnb[2] : dnb[3];
-    const unsigned nb1 = (x1 + d1) >> 16;
-    unsigned x2;
-    if (STRIDE == 1) {
-      x2 = size + ((unsigned)statebuf[i + 1] >> 1);
-    } else {
-      const int f1 = s1 == 0 ? dfs[0] : s1 == 1 ? dfs[1] : s1 == 2 ? dfs[2] : dfs[3];
-      x2 = st[(int)(x1 >> nb1) + f1];  // FSE_encodeSymbol's state update
-    }
-    const unsigned nb2 = (x2 + (s2 == 0 ? dnb[0] : s2 == 1 ? dnb[1] : s2 == 2 ? dnb[2] : dnb[3])) >> 16;
-    o[j >> 1] = ((nb1 << 12) | (x1 & ((1u << nb1) - 1u))) | (((nb2 << 12) | (x2 & ((1u << nb2) - 1u))) << 16);
-  }
-  return make_uint4(o[0], o[1], o[2], o[3]);
-}
-
-// The walker: one workgroup of two waves per PART.  Software pipeline over chunks, double-
-// buffered in LDS:
-//   wave 0, lane 0 : walks chunk k LDS -> LDS, recording only the state in front of every
-//                    (TWO: every even) symbol; raised issue priority
-//   wave 1         : turns (state, symbol) of chunk k-1 into the packed (nb, bits) outputs and
-//                    stores them with coalesced 16-byte stores, then stages the symbols of
-//                    chunk k+1 (coalesced 16-byte loads) and their table-row offsets
-// so the chain lane never waits on global memory and never computes an output.
-// TWO = false: one symbol per step (16 KB table).  TWO = true: two symbols per step through
-// T2 (64 KB at log 11; LDS footprint 76 KB -> two workgroups per CU).
-template <bool TWO>
-__global__ void __launch_bounds__(128)
-k_chain_seq(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-            const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ plan,
-            const SeqPart *__restrict__ parts, const uint32_t *__restrict__ ct,
-            const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state, StreamResult *res) {
-  constexpr unsigned CH = TWO ? 2048 : 1024;  // symbols per pipeline chunk (ONE: 26 KB of LDS -> 6 workgroups per CU)
-  extern __shared__ uint32_t lds[];
-  __shared__ uint4 symbuf[2][CH / 16];
-  __shared__ uint16_t statebuf[2][TWO ? CH / 2 : CH];  // (state - size) * 2
-  // byte offset of the table row every step reads: (symbol or symbol pair) << (log + 1),
-  // prepared by the helper wave so the walker's step is add + LDS read and nothing else
-  __shared__ uint16_t offbuf[2][TWO ? CH / 2 : CH];
-  constexpr unsigned B = SeqModel::B;
-  if (blockIdx.x >= plan[0]) return;  // the grid is an upper bound
-  const SeqPart part = parts[blockIdx.x];
-  const unsigned c = part.ctx, n = part.len;
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
+  const unsigned nf = fseg[c + 1] - fseg[c];
+  const unsigned k = (blockIdx.x - fitem[c]) * SETS_WAVES + wave;  // segment k of the chain
+  if (k >= nf) return;
+  SetsWaveLds &L = wl[wave];
+  const char *tbase = reinterpret_cast<const char *>(lds);
+  const unsigned per = max(size >> 6, 1u), nw = max(size >> 5, 1u);
+  const uint4 *gseg = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)k * S);
+  const unsigned nblk = S / SETS_BLOCK, w_end = S / 4;
+
+  // level 0: every state; lane l carries states l, l + 64, ...
+  unsigned x0[PER0];
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) x0[j] = ((lane + 64u * j) & (size - 1)) * 2u;
+  unsigned level = 0, n = size, n1 = 0;
+  unsigned w = 0, stop = 1;  // merge points after 4, 16, 48, 128, 512, 2048, 8192, ... symbols
+  uint4 cur = gseg[lane];
+  for (unsigned blk = 0; blk < nblk; blk++) {
+    const uint4 nxt = blk + 1 < nblk ? gseg[(size_t)(blk + 1) * 64 + lane] : cur;  // lands while cur is walked
+    const unsigned wb_end = (blk + 1) * (SETS_BLOCK / 4);
+    while (w < wb_end) {
+      const unsigned w1 = min(stop, wb_end);
+      if (level == 0) {
+        for (; w < w1; w++) {
+          const unsigned word = sets_word(cur, w);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const unsigned row = ((word >> (8 * i)) & 3u) << (log + 1);
+#pragma unroll
+            for (unsigned j = 0; j < PER0; j++)
+              if (j < per) x0[j] = *reinterpret_cast<const uint16_t *>(tbase + (row + x0[j]));
+          }
+        }
+      } else {
+        switch ((n + 63) / 64) {
+          case 1: sets_walk<1>(L, n, tbase, log, cur, w, w1); break;
+          case 2: sets_walk<2>(L, n, tbase, log, cur, w, w1); break;
+          case 3: sets_walk<3>(L, n, tbase, log, cur, w, w1); break;
+          case 4: sets_walk<4>(L, n, tbase, log, cur, w, w1); break;
+          case 5: sets_walk<5>(L, n, tbase, log, cur, w, w1); break;
+          case 6: sets_walk<6>(L, n, tbase, log, cur, w, w1); break;
+          case 7: sets_walk<7>(L, n, tbase, log, cur, w, w1); break;
+          default: sets_walk<8>(L, n, tbase, log, cur, w, w1); break;
+        }
+        w = w1;
+      }
+      if (w != stop || w >= w_end) continue;
+      stop = stop == 1 ? 4 : stop == 4 ? 12 : stop == 12 ? 32 : stop * 4;
+      if (level == 0) {
+        sets_clear(L);
+#pragma unroll
+        for (unsigned j = 0; j < PER0; j++)
+          if (j < per) { const unsigned xi = x0[j] >> 1; atomicOr(&L.bm[xi >> 5], 1u << (xi & 31u)); }
+        fq_lds_wave_sync();
+        const unsigned nn = sets_count(L, nw);
+        if (nn <= SETS_MAX_CLASSES) {  // from here on only the distinct states are carried
+#pragma unroll
+          for (unsigned j = 0; j < PER0; j++)
+            if (j < per) {
+              const unsigned r = sets_rank(L, x0[j] >> 1);
+              L.list[r] = (uint16_t)x0[j];
+              x0[j] = r;  // class of entry state lane + 64 j
+            }
+          for (unsigned i = lane; i < nn; i += 64) L.m[i] = (uint16_t)i;
+          fq_lds_wave_sync();
+          level = 1; n = n1 = nn;
+        }
+      } else if (n > 64) {
+        n = sets_merge(L, n, n1, nw);
+      }
+    }
+    cur = nxt;
+  }
+  // F[entry] = exit, both as (state - size) * 2
+  uint16_t *f = fbuf + (size_t)(fseg[c] + k) * fstride;
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) {
+    const unsigned xi = lane + 64u * j;
+    if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
+  }
+}
+
+// Step B: entry state of every segment of every chain
+__global__ void __launch_bounds__(256)
+k_seq_resolve(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, unsigned fstride,
+              uint16_t *__restrict__ entry) {
+  constexpr unsigned B = SeqModel::B;
+  const uint32_t *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1);
+  const unsigned c = threadIdx.x;
+  const unsigned ns = seg[c + 1] - seg[c];
+  unsigned xo = 0;  // FSE_initCState: state = size
+  for (unsigned k = 0; k < ns; k++) {
+    entry[seg[c] + k] = (uint16_t)xo;
+    if (k + 1 < ns) xo = fbuf[(size_t)(fseg[c] + k) * fstride + (xo >> 1)];
+  }
+}
+
+// Step C: one lane per segment, 64 segments of one context per wave
+__global__ void __launch_bounds__(64)
+k_seq_emit(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
+           const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ plan,
+           const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
+           const uint16_t *__restrict__ next1, unsigned next_stride, unsigned S,
+           const uint16_t *__restrict__ entry, uint16_t *__restrict__ final_state, StreamResult *res) {
+  extern __shared__ uint32_t lds[];
+  constexpr unsigned B = SeqModel::B;
+  const uint32_t *seg = plan + 2 * (B + 1), *eitem = plan + 3 * (B + 1);
+  if (blockIdx.x >= eitem[B]) return;  // the grid is an upper bound
+  const unsigned c = seq_item_ctx(eitem, blockIdx.x);
   const uint32_t *tbl = ct + ct_off[c];
   const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
-  const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(next1 + (size_t)c * next_stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (unsigned e = threadIdx.x; e < size / 2; e += 64) dst[e] = src[e];
+  }
   const uint32_t *tt = tbl + 1 + (size >> 1);
   unsigned dnb[4];
-  int dfs[4];
 #pragma unroll
-  for (int s = 0; s < 4; s++) { dfs[s] = (int)tt[2 * s]; dnb[s] = tt[2 * s + 1]; }
-  uint16_t *table = reinterpret_cast<uint16_t *>(lds);  // ONE: next[4][size]; TWO: T2[16][size]
-  if (!TWO) {
-    build_next1(table, tbl, log, 128);
-  } else {
-    // T2 is built from the one-symbol table, which is parked in the LAST quarter of the T2
-    // area: the first three quarters are written while it is read, the last quarter is computed
-    // into registers, and only then overwritten
-    uint16_t *next = table + 12 * size;
-    build_next1(next, tbl, log, 128);
-    __syncthreads();
-    const char *nb1 = reinterpret_cast<const char *>(next);
-    auto t2_entry = [&](unsigned e) -> uint16_t {
-      const unsigned xi = e & (size - 1), s1 = (e >> log) & 3u, s2 = e >> (log + 2);
-      const unsigned mid = next[(s1 << log) + xi];
-      return *reinterpret_cast<const uint16_t *>(nb1 + ((s2 << (log + 1)) + mid));
-    };
-    for (unsigned e = threadIdx.x; e < 12 * size; e += 128) table[e] = t2_entry(e);
-    uint16_t keep[(4u << FQ_MAX_LOG_T2) / 128];
-#pragma unroll
-    for (unsigned k = 0; k < (4u << FQ_MAX_LOG_T2) / 128; k++) {
-      const unsigned e = 12 * size + k * 128 + threadIdx.x;
-      keep[k] = e < 16 * size ? t2_entry(e) : (uint16_t)0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (unsigned k = 0; k < (4u << FQ_MAX_LOG_T2) / 128; k++) {
-      const unsigned e = 12 * size + k * 128 + threadIdx.x;
-      if (e < 16 * size) table[e] = keep[k];
-    }
-  }
-  const char *tbase = reinterpret_cast<const char *>(table);
-  const size_t run0 = (size_t)arrays[B + c] + part.begin;  // 16-byte aligned (CTX_PAD, COMPOSE_CHUNK)
+  for (int s = 0; s < 4; s++) dnb[s] = tt[2 * s + 1];
+  fq_lds_wave_sync();
+  const unsigned n = arrays[c], ns = seg[c + 1] - seg[c];
+  const unsigned k = (blockIdx.x - eitem[c]) * 64 + fq_lane();
+  if (k >= ns) return;
+  const char *tbase = reinterpret_cast<const char *>(lds);
+  const size_t run0 = (size_t)arrays[B + c] + (size_t)k * S;  // 16-byte aligned
+  const unsigned len = min(S, n - k * S);
   const uint4 *gsym = reinterpret_cast<const uint4 *>(sorted_sym + run0);
   uint4 *gout = reinterpret_cast<uint4 *>(out16 + run0);
-  const unsigned n_chunks = (n + CH - 1) / CH;
-  // symbols of chunk kn -> symbuf + row offsets (the run is padded to 16: reading the pad is harmless)
-  auto stage = [&](unsigned kn) {
-    const unsigned q16 = (min(CH, n - kn * CH) + 15) >> 4;
-    for (unsigned v = lane; v < q16; v += 64) {
-      const uint4 sv = gsym[kn * (CH / 16) + v];
-      symbuf[kn & 1][v] = sv;
-      const unsigned w[4] = {sv.x, sv.y, sv.z, sv.w};
-      unsigned o[8];
-      if (TWO) {
+  unsigned xo = entry[seg[c] + k];
+  const unsigned groups = (len + 15) >> 4;  // the run is padded to 16: the pad is walked and never read back
+  uint4 sv = gsym[0];
+  for (unsigned g = 0; g < groups; g++) {
+    const uint4 sv_next = gsym[g + 1 < groups ? g + 1 : g];
+    const unsigned wds[4] = {sv.x, sv.y, sv.z, sv.w};
+    unsigned o[8];
+    const unsigned live = min(16u, len - g * 16);
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const unsigned word = w[j >> 1];  // four symbols = two pairs
-          const unsigned pc0 = (word & 3u) | ((word >> 6) & 0xCu), pc1 = ((word >> 16) & 3u) | ((word >> 22) & 0xCu);
-          o[j >> 1] = (pc0 << (log + 1)) | ((pc1 << (log + 1)) << 16);
-        }
-        reinterpret_cast<uint4 *>(offbuf[kn & 1])[v] = make_uint4(o[0], o[1], o[2], o[3]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-          const unsigned s0 = (w[j >> 2] >> (8 * (j & 3))) & 3u, s1 = (w[j >> 2] >> (8 * ((j + 1) & 3))) & 3u;
-          o[j >> 1] = (s0 << (log + 1)) | ((s1 << (log + 1)) << 16);
-        }
-        reinterpret_cast<uint4 *>(offbuf[kn & 1])[2 * v] = make_uint4(o[0], o[1], o[2], o[3]);
-        reinterpret_cast<uint4 *>(offbuf[kn & 1])[2 * v + 1] = make_uint4(o[4], o[5], o[6], o[7]);
-      }
+    for (int j = 0; j < 16; j++) {
+      const unsigned s = (wds[j >> 2] >> (8 * (j & 3))) & 3u;
+      const unsigned x = size + (xo >> 1);
+      const unsigned nb = (x + (s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3])) >> 16;
+      const unsigned v = (nb << 12) | (x & ((1u << nb) - 1u));
+      if (j & 1) o[j >> 1] |= v << 16; else o[j >> 1] = v;
+      const unsigned nx = *reinterpret_cast<const uint16_t *>(tbase + ((s << (log + 1)) + xo));
+      if ((unsigned)j < live) xo = nx;  // the state stops at the end of the chain
     }
-  };
-  if (wave == 1) stage(0);  // prologue
-  __syncthreads();
-  unsigned xo = part.start_xo;  // (state - size) * 2, meaningful in wave 0 lane 0 only
-  // the walker is the critical path of the whole block: it wins issue arbitration against
-  // whatever else shares its SIMD
-  if (wave == 0) __builtin_amdgcn_s_setprio(3);
-  // one FSE_encodeSymbol transition straight from the CTable (ragged tail only)
-  auto step1 = [&](unsigned s, unsigned cur) -> unsigned {
-    const unsigned x = size + (cur >> 1);
-    const unsigned d = s == 0 ? dnb[0] : s == 1 ? dnb[1] : s == 2 ? dnb[2] : dnb[3];
-    const int f = s == 0 ? dfs[0] : s == 1 ? dfs[1] : s == 2 ? dfs[2] : dfs[3];
-    const unsigned nb = (x + d) >> 16;
-    return ((unsigned)st[(int)(x >> nb) + f] - size) * 2u;
-  };
-  for (unsigned k = 0; k <= n_chunks; k++) {
-    if (wave == 0) {
-      if (lane == 0 && k < n_chunks) {
-        const unsigned len = min(CH, n - k * CH);
-        const unsigned q16 = (len + 15) >> 4, full = len >> 4;
-        const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf[k & 1]);
-        uint16_t *stb = statebuf[k & 1];
-        uint4 *state4 = reinterpret_cast<uint4 *>(stb);
-        const uint4 *off4 = reinterpret_cast<const uint4 *>(offbuf[k & 1]);
-        if (TWO) {
-          uint4 ov = off4[0];
-          for (unsigned g = 0; g < full; g++) {  // 16 symbols = 8 pair steps
-            const uint4 ov_next = off4[g + 1 < q16 ? g + 1 : g];  // lands while this group is walked
-            const unsigned w[4] = {ov.x, ov.y, ov.z, ov.w};
-            unsigned xs[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-              xs[j] = xo;
-              xo = *reinterpret_cast<const uint16_t *>(tbase + (((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + xo));
-            }
-            state4[g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
-            ov = ov_next;
-          }
-        } else {
-          uint4 ov0 = off4[0], ov1 = off4[1];
-          for (unsigned g = 0; g < full; g++) {  // 16 one-symbol steps
-            const unsigned gn = g + 1 < q16 ? g + 1 : g;
-            const uint4 n0 = off4[2 * gn], n1 = off4[2 * gn + 1];
-            const unsigned w[8] = {ov0.x, ov0.y, ov0.z, ov0.w, ov1.x, ov1.y, ov1.z, ov1.w};
-            unsigned xs[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-              xs[j] = xo;
-              xo = *reinterpret_cast<const uint16_t *>(tbase + (((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + xo));
-            }
-            state4[2 * g] = make_uint4(xs[0] | (xs[1] << 16), xs[2] | (xs[3] << 16), xs[4] | (xs[5] << 16), xs[6] | (xs[7] << 16));
-            state4[2 * g + 1] = make_uint4(xs[8] | (xs[9] << 16), xs[10] | (xs[11] << 16), xs[12] | (xs[13] << 16), xs[14] | (xs[15] << 16));
-            ov0 = n0; ov1 = n1;
-          }
-        }
-        // ragged end of the last chunk, one symbol at a time (TWO: the partner state of an even
-        // symbol is recomputed by the output pass, so only even positions are recorded)
-        for (unsigned i = full << 4; i < len; i++) {
-          const unsigned s = sbytes[i] & 3u;
-          if (!TWO) stb[i] = (uint16_t)xo;
-          else if (!(i & 1u)) stb[i >> 1] = (uint16_t)xo;
-          xo = step1(s, xo);
-        }
-      }
-    } else {
-      if (k >= 1) {  // outputs of chunk k-1
-        const unsigned kk = k - 1;
-        const unsigned len = min(CH, n - kk * CH);
-        const unsigned q8 = (len + 7) >> 3;
-        const uint8_t *sbytes = reinterpret_cast<const uint8_t *>(symbuf[kk & 1]);
-        for (unsigned v = lane; v < q8; v += 64)
-          gout[kk * (CH / 8) + v] = seq_outputs8<TWO ? 2 : 1>(sbytes, statebuf[kk & 1], st, dfs, v, size, dnb);
-      }
-      if (k + 1 < n_chunks) stage(k + 1);  // into the buffers whose outputs were just produced
-    }
-    __syncthreads();
+    gout[2 * g] = make_uint4(o[0], o[1], o[2], o[3]);
+    gout[2 * g + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    sv = sv_next;
   }
-  if (threadIdx.x == 0) {
-    if (part.last) final_state[c] = (uint16_t)(size + (xo >> 1));
-    atomicMax(&res->refixed, n);
-  }
+  if (k == ns - 1) final_state[c] = (uint16_t)(size + (xo >> 1));
+  if (fq_lane() == 0) atomicMax(&res->refixed, len);
 }
 
 // ------------------------------------------------------------------ K6: bit offsets and packing
@@ -1067,9 +1054,14 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if ((rc = sc.group_sum.reserve((size_t)n_groups * B * 4))) return rc;
   if ((rc = sc.ctx_arrays.reserve((size_t)(4 * B + 3) * 4))) return rc;
   if ((rc = sc.seg_state.reserve((size_t)B * 2 + (size_t)B * 8))) return rc;
+  // sequence chains: segment length of the candidate-set kernels
+  unsigned seq_S = ctx->seq_segment ? ctx->seq_segment : 4096u;
+  seq_S = (unsigned)min(((size_t)seq_S + SETS_BLOCK - 1) / SETS_BLOCK * SETS_BLOCK, (size_t)1 << 30);
+  const unsigned seq_max_segs = n_sym / seq_S + B + 1;
+  const unsigned seq_fstride = 1u << tab.max_log;
   if (M::STREAM == 0) {
-    if ((rc = sc.seq_plan.reserve((size_t)PLAN_WORDS * 4 + ((size_t)B + n_sym / COMPOSE_CHUNK + 2) * sizeof(SeqPart)))) return rc;
-    if ((rc = sc.seq_fbuf.reserve(((size_t)n_sym / COMPOSE_CHUNK + 2) * (2u << FQ_MAX_LOG_SEQ)))) return rc;
+    if ((rc = sc.seq_plan.reserve((size_t)SEGPLAN_WORDS * 4 + (size_t)seq_max_segs * 2 + 64))) return rc;
+    if ((rc = sc.seq_fbuf.reserve((size_t)seq_max_segs * seq_fstride * 2 + 64))) return rc;
   }
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
   if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
@@ -1098,35 +1090,32 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
                      sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : (serial_seq ? "seq.compose" : "seq.chains"));
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : (serial_seq ? "seq.setfunc" : "seq.chains"));
   if (serial_seq) {
-    // plan: long chains are split into parts of about the average chain length; the start
-    // state of every part comes from composed chunk functions (k_seq_compose / k_seq_apply)
     uint32_t *plan = sc.seq_plan.as<uint32_t>();
-    SeqPart *parts = reinterpret_cast<SeqPart *>(plan + PLAN_WORDS);
-    const unsigned max_comp = n_sym / COMPOSE_CHUNK + 1;
-    // same rounding as k_seq_plan: upper bound of the number of parts
-    unsigned part_len = ctx->seq_part_target ? ctx->seq_part_target : max(n_sym / B, COMPOSE_CHUNK);
-    part_len = ((part_len + COMPOSE_CHUNK - 1) / COMPOSE_CHUNK) * COMPOSE_CHUNK;
-    const unsigned max_parts = B + n_sym / part_len + 1;
+    uint16_t *entry = reinterpret_cast<uint16_t *>(plan + SEGPLAN_WORDS);
     uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
-    const bool two = tab.max_log <= FQ_MAX_LOG_T2 && !ctx->seq_one_symbol;
+    const unsigned next_stride = 4u << tab.max_log;
+    const unsigned max_fitems = seq_max_segs / SETS_WAVES + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
     static const bool dbg_skip = getenv("FQGPU_DEBUG_SKIP_SEQ_CHAIN") != nullptr;  // timing experiment only: wrong output
-    hipLaunchKernelGGL(k_seq_plan, dim3(1), dim3(256), 0, st, arrays, n_sym, ctx->seq_part_target, plan, parts);
+    hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, plan);
     if (!dbg_skip) {
-      hipLaunchKernelGGL(k_seq_compose, dim3(max_comp), dim3(256), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
-                         arrays, plan, tab.ct, tab.ct_off, fbuf);
-      hipLaunchKernelGGL(k_seq_apply, dim3(1), dim3(256), 0, st, plan, fbuf, parts);
+      if (tab.max_log <= 11)
+        hipLaunchKernelGGL(k_seq_setfunc<32>, dim3(max_fitems), dim3(SETS_WAVES * 64), 8u << tab.max_log, st,
+                           sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1, next_stride, seq_S,
+                           seq_fstride, fbuf);
+      else
+        hipLaunchKernelGGL(k_seq_setfunc<64>, dim3(max_fitems), dim3(SETS_WAVES * 64), 8u << tab.max_log, st,
+                           sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1, next_stride, seq_S,
+                           seq_fstride, fbuf);
+      FQ_SPAN_END();
+      FQ_SPAN_BEGIN("seq.resolve");
+      hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, entry);
       FQ_SPAN_END();
       FQ_SPAN_BEGIN("seq.chains");
-      if (two)
-        hipLaunchKernelGGL(k_chain_seq<true>, dim3(max_parts), dim3(128), 32u << tab.max_log, st,
-                           sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, plan, parts, tab.ct,
-                           tab.ct_off, final_state, res);
-      else
-        hipLaunchKernelGGL(k_chain_seq<false>, dim3(max_parts), dim3(128), 8u << tab.max_log, st,
-                           sc.sorted_sym.as<uint8_t>(), sc.out16.as<uint16_t>(), arrays, plan, parts, tab.ct,
-                           tab.ct_off, final_state, res);
+      hipLaunchKernelGGL(k_seq_emit, dim3(max_eitems), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
+                         sc.out16.as<uint16_t>(), arrays, plan, tab.ct, tab.ct_off, tab.next1, next_stride, seq_S,
+                         entry, final_state, res);
     }
   } else {
     hipLaunchKernelGGL(k_chains_reset<M>, dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),

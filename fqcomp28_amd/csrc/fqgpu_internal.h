@@ -34,6 +34,8 @@ struct DevTables {
   uint32_t *ct_off = nullptr;   // [B] word offset of each CTable
   uint32_t *dt = nullptr;       // DTable pool, zstd word layout per context
   uint32_t *dt_off = nullptr;   // [B]
+  uint16_t *next1 = nullptr;    // sequence stream only: [B][4 << max_log] one-symbol transition tables,
+                                // next[s][x - size] = ((state after coding s in state x) - size) * 2
   uint32_t max_log = 0;
   size_t ct_words = 0, dt_words = 0;
 };
@@ -99,8 +101,8 @@ struct EncScratch {
   DevBuf group_sum;   // u32 [groups][B]
   DevBuf ctx_arrays;  // ctx_count[B], ctx_start[B+1], seg_base[B+1], item_base[B+1]
   DevBuf seg_state;   // u16 final_state[B]
-  DevBuf seq_plan;    // plan words + SeqPart[2B] (sequence stream: parts of split chains)
-  DevBuf seq_fbuf;    // u16 [compose chunks][4096] composed chunk functions
+  DevBuf seq_plan;    // segment plan of the sequence chains (encode.hip: SEGPLAN_WORDS) + entry states
+  DevBuf seq_fbuf;    // u16 [segments][1 << max_log] segment functions F: entry state -> exit state
   DevBuf tile_bits;   // u32 [ptiles]
   DevBuf tile_bit_base;  // u64 [ptiles+1]
   DevBuf scan_tmp;    // u64 chunk sums for the scans
@@ -127,8 +129,7 @@ struct fqgpu_ctx {
   DevTables tab[2];
   unsigned seg_len = 1024;       // nominal segment of the reset-cut chain kernel
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
-  int seq_one_symbol = 0;        // 1: serial sequence kernel with one symbol per step (no T2 table)
-  unsigned seq_part_target = 0;  // part length of split sequence chains (0 = average chain of the block)
+  unsigned seq_segment = 0;      // segment length of the sequence chain kernels (0 = default)
   unsigned n_lanes = 4, next_lane = 0;
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch

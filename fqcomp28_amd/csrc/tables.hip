@@ -420,6 +420,24 @@ int fq_normalize_counts(hipStream_t st, const uint32_t *counts_dev, int n_models
   return FQGPU_OK;
 }
 
+// One-symbol transition tables of the sequence contexts (FSE_encodeSymbol's state update,
+// zstd fse.h, tabulated): next[s][x - size] = (stateTable[(x >> nb) + deltaFindState] - size) * 2,
+// nb = (x + deltaNbBits) >> 16.  Stored pre-scaled to the byte offset of the following lookup.
+__global__ void __launch_bounds__(256)
+k_build_seq_next(const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, unsigned stride,
+                 uint16_t *__restrict__ next1) {
+  const uint32_t *tbl = ct + ct_off[blockIdx.x];
+  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
+  const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
+  const uint32_t *tt = tbl + 1 + (size >> 1);
+  uint16_t *next = next1 + (size_t)blockIdx.x * stride;
+  for (unsigned e = threadIdx.x; e < 4 * size; e += 256) {
+    const unsigned s = e >> log, x = size + (e & (size - 1));
+    const unsigned nb = (x + tt[2 * s + 1]) >> 16;
+    next[e] = (uint16_t)(((unsigned)st[(int)(x >> nb) + (int)tt[2 * s]] - size) * 2u);
+  }
+}
+
 // t.norm and t.logs are already on the device; allocates and fills everything else
 int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint32_t *err_dev) {
   const unsigned B = (unsigned)n_models;
@@ -447,6 +465,12 @@ int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint3
   else
     hipLaunchKernelGGL((k_build_tables<FQGPU_QUAL_ALPHA, 6>), dim3(B), dim3(64), 0, st, t.norm, t.logs, t.ct_off,
                        t.dt_off, t.ct, t.dt, err_dev);
+  if (alpha == FQGPU_SEQ_ALPHA) {
+    const unsigned stride = 4u << t.max_log;
+    t.next1 = fq_dev_alloc<uint16_t>((size_t)B * stride + 64);
+    if (!t.next1) return FQGPU_E_NOMEM;
+    hipLaunchKernelGGL(k_build_seq_next, dim3(B), dim3(256), 0, st, t.ct, t.ct_off, stride, t.next1);
+  }
   FQ_HIP(hipGetLastError());
   return FQGPU_OK;
 }

@@ -86,16 +86,14 @@ void fqgpu_ctx_destroy(fqgpu_ctx *ctx);
 /* Tuning knobs of the state-chain kernels; results never depend on them.
  * segment: nominal length, in symbols, of the pieces a context's chain is cut into at
  * single-state ("reset") symbols (0 keeps the default).  flags: FQGPU_CHAIN_SEQ_GENERIC
- * runs the sequence stream through the same reset-cut kernel instead of the serial
- * one-lane-per-context kernels (two symbols per step through a 64 KB LDS table by default;
- * one symbol per step with FQGPU_CHAIN_SEQ_ONE_SYMBOL or when a table log exceeds 11). */
+ * runs the sequence stream through the same reset-cut kernel instead of the segment-function
+ * kernels (sequence tables have no single-state symbols: every chain is then walked by one lane). */
 #define FQGPU_CHAIN_SEQ_GENERIC 1u
-#define FQGPU_CHAIN_SEQ_ONE_SYMBOL 2u /* serial sequence kernel without the two-symbol table */
 int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned flags);
-/* Sequence chains longer than ~1.125x `symbols` are split into parts of about that length whose
- * exact start states come from composed chunk functions (0 = the block's average chain length;
- * rounded up to a multiple of 4096).  Results never depend on it. */
-int fqgpu_ctx_set_seq_part_target(fqgpu_ctx *ctx, unsigned symbols);
+/* Segment length, in symbols, of the sequence chain kernels: every chain is cut into segments
+ * whose exact entry states come from per-segment state functions (0 = default 4096; rounded up
+ * to a multiple of 1024).  Results never depend on it. */
+int fqgpu_ctx_set_seq_segment(fqgpu_ctx *ctx, unsigned symbols);
 /* Number of blocks the handle keeps in flight (encode lanes, 1..8, default 4): each
  * fqgpu_dblock_encode goes to the next lane (own HIP streams and scratch). */
 int fqgpu_ctx_set_lanes(fqgpu_ctx *ctx, unsigned lanes);

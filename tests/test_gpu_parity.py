@@ -133,13 +133,13 @@ def test_tables_from_counts_normalisation_corner_cases(F):
 
 # ---------------------------------------------------------------- how the chains are cut never shows in the output
 @pytest.mark.parametrize("seg,seq_generic,lanes", [(2, True, 1), (16, True, 3), (64, False, 2), (100000, True, 1),
-                                                   (1024, False, 4), (1024, "one", 2)])
+                                                   (1024, False, 4)])
 def test_chain_parameters_never_change_the_bits(F, golden_dir, seg, seq_generic, lanes):
     raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_2.fastq"))
     _, _, sft, qft = O.freq_tables(raw, recs)
     e = O.OracleCtx(sft, qft).encode(raw, recs)
     ctx = F.Context(sft, qft)
-    ctx.set_chain_params(seg, seq_generic is True, seq_generic == "one")
+    ctx.set_chain_params(seg, seq_generic)
     ctx.set_lanes(lanes)
     blocks = [ctx.dblock(raw, recs) for _ in range(3)]  # several blocks in flight on the lanes
     for b in blocks:
@@ -195,19 +195,47 @@ def test_config1_uniform_q40_degenerate_context(F):
     ctx.close()
 
 
-@pytest.mark.parametrize("part_target", [4096, 20000, 1 << 30])
-def test_split_sequence_chains_are_exact(F, part_target):
-    """Long sequence chains are split into parts whose start states come from composed chunk
-    functions (k_seq_compose / k_seq_apply): any part length gives the same bits."""
+def _rewrite_bases(raw, recs, make):
+    """synthetic block with its bases replaced by make(n) -> uint8 codes 0..3 (A, C, G, T)"""
+    raw = raw.copy()
+    n = int(recs["len"].sum())
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[make(n)]
+    at = 0
+    for r in recs:
+        raw[r["seq_off"]: r["seq_off"] + r["len"]] = letters[at: at + r["len"]]
+        at += int(r["len"])
+    return raw
+
+
+@pytest.mark.parametrize("bases", ["uniform", "skewed", "markov", "all_A", "mostly_A"])
+@pytest.mark.parametrize("segment", [1024, 4096, 20000, 1 << 30])
+def test_sequence_segment_functions_are_exact(F, bases, segment):
+    """The sequence chains are cut into segments whose entry states come from per-segment state
+    functions (k_seq_setfunc / k_seq_resolve / k_seq_emit): any segment length gives the oracle's
+    bits, for near-uniform tables (the state sets stay large), skewed ones (they collapse fast) and
+    single-symbol contexts (no state ever merges: the function is carried for all 2^log states)."""
     raw, recs = _synth(F, 2, 6 << 20)
+    rng = np.random.default_rng(5)
+    if bases == "skewed":
+        raw = _rewrite_bases(raw, recs, lambda n: rng.choice(4, size=n, p=[0.55, 0.05, 0.1, 0.3]))
+    elif bases == "markov":
+        def chain(n):  # 70 %: repeat the previous base, else a fresh uniform one
+            fresh = rng.integers(0, 4, size=n)
+            keep = rng.random(n) < 0.7
+            keep[0] = False
+            return fresh[np.maximum.accumulate(np.where(keep, 0, np.arange(n)))]
+        raw = _rewrite_bases(raw, recs, chain)
+    elif bases == "all_A":
+        raw = _rewrite_bases(raw, recs, lambda n: np.zeros(n, dtype=np.int64))
+    elif bases == "mostly_A":
+        raw = _rewrite_bases(raw, recs, lambda n: rng.choice(4, size=n, p=[0.997, 0.001, 0.001, 0.001]))
     _, _, sft, qft = O.freq_tables(raw, recs)
     e = O.OracleCtx(sft, qft).encode(raw, recs)
-    for one_symbol in (False, True):
-        ctx = F.Context(sft, qft)
-        ctx.set_chain_params(0, seq_one_symbol=one_symbol, seq_part_target=part_target)
-        g = ctx.encode_block(raw, recs)
-        assert_same_encoding(g, e)
-        ctx.close()
+    ctx = F.Context(sft, qft)
+    ctx.set_chain_params(0, seq_segment=segment)
+    g = ctx.encode_block(raw, recs)
+    assert_same_encoding(g, e)
+    ctx.close()
 
 
 @pytest.mark.parametrize("mode,size", [(2, 12 << 20), (4, 12 << 20)])

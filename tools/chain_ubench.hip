@@ -110,7 +110,7 @@ int main() {
   CK(hipMemcpy(dtab1, tab1.data(), tab.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(dsym, sym.data(), sym.size(), hipMemcpyHostToDevice));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int grid : {1, 256, 1024, 2048}) {
+  for (int grid : {1, 256}) {
     for (int var = 0; var < 4; var++) {
       for (int rep = 0; rep < 2; rep++) {
         CK(hipEventRecord(a));
@@ -127,7 +127,7 @@ int main() {
       }
     }
   }
-  for (int grid : {1, 16, 512}) {
+  for (int grid : {1, 256, 512, 768, 1024}) {
     for (int pack = 0; pack < 2; pack++) {
       for (int rep = 0; rep < 2; rep++) {
         CK(hipEventRecord(a));
