@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--seq-mode", default="sets", choices=["sets", "generic"],
                     help="sequence chain kernels: segment functions over state sets (default), reset-cut kernel")
     ap.add_argument("--seq-segment", type=int, default=None, help="segment length of the sequence chain kernels")
+    ap.add_argument("--segment", type=int, default=0, help="segment length of the generic (quality) chain kernels")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank); gloo only to rehearse the "
                     "multi-rank path on a one-GPU box (all ranks then share GPU 0)")
     ap.add_argument("--skip-decode", action="store_true")
@@ -143,7 +144,7 @@ def main():
     sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
     ctx = F.Context(sft, qft, device=device)
     ctx.set_lanes(max(1, min(args.lanes, 8)))
-    ctx.set_chain_params(0, seq_generic=args.seq_mode == "generic", seq_segment=args.seq_segment)
+    ctx.set_chain_params(args.segment, seq_generic=args.seq_mode == "generic", seq_segment=args.seq_segment)
     dblocks = [ctx.dblock(raw, recs) for raw, recs in blocks]
     raw_bytes = sum(raw.size for raw, _ in blocks)
     n_recs = sum(len(r) for _, r in blocks)

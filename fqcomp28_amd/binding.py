@@ -32,8 +32,8 @@ class FqgpuError(RuntimeError):
 
 
 class Timing(C.Structure):
-    _fields_ = [("total_ms", C.c_float), ("kernel_ms", C.c_float * 24), ("kernel_calls", C.c_int * 24),
-                ("kernel_name", C.c_char_p * 24), ("n_kernels", C.c_int)]
+    _fields_ = [("total_ms", C.c_float), ("kernel_ms", C.c_float * 32), ("kernel_calls", C.c_int * 32),
+                ("kernel_name", C.c_char_p * 32), ("n_kernels", C.c_int)]
 
 
 def lib_path():

@@ -136,7 +136,7 @@ extern "C" int fqgpu_ctx_last_timing(fqgpu_ctx *ctx, fqgpu_timing *out) {
     int k = 0;
     for (; k < out->n_kernels; k++) if (strcmp(out->kernel_name[k], sp.name) == 0) break;
     if (k == out->n_kernels) {
-      if (k == 24) continue;
+      if (k == 32) continue;
       out->kernel_name[k] = sp.name;
       out->n_kernels++;
     }
@@ -171,7 +171,7 @@ static void free_lane(EncLane &l) {
   for (int s = 0; s < 2; s++) {
     EncScratch &e = l.enc[s];
     DevBuf *eb[] = {&e.slot_of, &e.keys, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
-                    &e.ctx_arrays, &e.seg_state, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
+                    &e.ctx_arrays, &e.seg_state, &e.seg_arrays, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
     for (DevBuf *b : eb) b->release();
   }
   hipEvent_t evs[] = {l.ev_fork, l.ev_join};
@@ -290,7 +290,7 @@ extern "C" int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len,
 
 // ------------------------------------------------------------------ handle
 static void free_tables(DevTables &t) {
-  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off, t.next1};
+  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off, t.next1, t.reset_mask};
   for (void *p : ps) if (p) (void)hipFree(p);
   t = DevTables();
 }

@@ -392,110 +392,9 @@ __device__ __forceinline__ unsigned chain_step(const LdsCTable &t, unsigned &x, 
   return out;
 }
 
-// A symbol with normalised count 1 or -1 owns ONE table cell: deltaNbBits = (log<<16) - size,
-// every state emits `log` bits and lands on stateTable[1 + deltaFindState].
-__device__ __forceinline__ bool is_reset_symbol(const LdsCTable &t, unsigned sym) {
-  return t.tt[2 * sym + 1] == (t.log << 16) - (1u << t.log);
-}
+// the one cell of a symbol with normalised count 1 or -1: stateTable[1 + deltaFindState]
 __device__ __forceinline__ unsigned reset_state(const LdsCTable &t, unsigned sym) {
   return t.state_table[1 + (int)t.tt[2 * sym]];
-}
-
-// Generic chain kernel: the chain of a context is cut into nominal segments of S symbols,
-// 64 of them per wave.  The lane of segment k starts at the first position of its segment
-// whose predecessor is a reset symbol (or at 0 for k == 0) and keeps going -- across
-// segment borders -- until the next lane's start point.  Lanes without a start point idle:
-// their symbols are covered by the lane before.  Exact by construction, no verification.
-template <class M>
-__global__ void __launch_bounds__(64)
-k_chains_reset(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-               const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
-               const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state, unsigned S,
-               StreamResult *res) {
-  extern __shared__ uint32_t lds[];
-  constexpr unsigned B = M::B;
-  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
-                 *item_base = seg_base + B + 1;
-  const unsigned item = blockIdx.x;
-  if (item >= item_base[B]) return;  // the grid is an upper bound
-  unsigned lo = 0, hi = B - 1;       // context owning this work item: last c with item_base[c] <= item
-  while (lo < hi) {
-    const unsigned mid = lo + ((hi - lo + 1) >> 1);
-    if (item_base[mid] <= item) lo = mid; else hi = mid - 1;
-  }
-  const unsigned c = lo;
-  const unsigned n = ctx_count[c];
-  const unsigned nseg = (n + S - 1) / S;
-  const unsigned k = (item - item_base[c]) * 64 + fq_lane();
-  const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
-  if (k >= nseg) return;
-  const uint8_t *sym = sorted_sym + ctx_start[c];
-  uint16_t *out = out16 + ctx_start[c];
-  const unsigned begin = k * S, end = min(n, begin + S);
-  // start point of this segment
-  unsigned i = begin, x = 1u << t.log;  // FSE_initCState for k == 0
-  if (k > 0) {
-    bool found = false;
-    for (unsigned j = begin; j < end; j++) {
-      const unsigned prev = sym[j - 1];
-      if (is_reset_symbol(t, prev)) { i = j; x = reset_state(t, prev); found = true; break; }
-    }
-    if (!found) return;
-  }
-  // The walk, 16 symbols per 16-byte load and two 16-byte stores per full group (the run of
-  // a context is 16-byte aligned); only the ragged head and tail of a piece use 2-byte stores.
-  unsigned steps = 0;
-  bool done = false;
-  // head: up to the next multiple of 16
-  while (!done && (i & 15u)) {
-    const unsigned sy = sym[i];
-    out[i] = (uint16_t)chain_step(t, x, sy);
-    i++; steps++;
-    if (i >= n) { final_state[c] = (uint16_t)x; done = true; }
-    else if (i >= end && is_reset_symbol(t, sy)) done = true;
-  }
-  if (!done) {
-    const uint4 *sym16 = reinterpret_cast<const uint4 *>(sym);
-    uint4 *out16v = reinterpret_cast<uint4 *>(out);
-    uint4 cur = sym16[i >> 4];
-    while (!done && i + 16 <= n) {
-      const uint4 nxt = (i + 32 <= n + 15u) ? sym16[(i >> 4) + 1] : cur;  // padded run: safe to read
-      const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
-      unsigned o[8];
-      int stop_at = -1;  // index inside the group after which this lane's piece ends
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        if (stop_at < 0) {  // predicated, no break: keeps o[] and w[] in registers
-          const unsigned sy = (w[j >> 2] >> (8 * (j & 3))) & (unsigned)(M::A - 1);
-          const unsigned v = chain_step(t, x, sy);
-          if (j & 1) o[j >> 1] |= v << 16; else o[j >> 1] = v;
-          if (i + j + 1 >= end && i + j + 1 < n && is_reset_symbol(t, sy)) stop_at = j;
-        }
-      }
-      if (stop_at < 0) {
-        out16v[i >> 3] = make_uint4(o[0], o[1], o[2], o[3]);
-        out16v[(i >> 3) + 1] = make_uint4(o[4], o[5], o[6], o[7]);
-        i += 16; steps += 16;
-        cur = nxt;
-      } else {  // the next lane starts inside this group: commit only our symbols
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-          if (j <= stop_at) out[i + j] = (uint16_t)(o[j >> 1] >> (16 * (j & 1)));
-        i += (unsigned)stop_at + 1; steps += (unsigned)stop_at + 1;
-        done = true;
-      }
-    }
-    if (!done && i >= n) { final_state[c] = (uint16_t)x; done = true; }
-    // tail: fewer than 16 symbols left in the chain
-    while (!done) {
-      const unsigned sy = sym[i];
-      out[i] = (uint16_t)chain_step(t, x, sy);
-      i++; steps++;
-      if (i >= n) { final_state[c] = (uint16_t)x; done = true; }
-      else if (i >= end && is_reset_symbol(t, sy)) done = true;
-    }
-  }
-  atomicMax(&res->refixed, steps);  // longest serial run (diagnostic)
 }
 
 // ---- sequence chains -------------------------------------------------------------------
@@ -628,13 +527,18 @@ __device__ __forceinline__ void sets_walk(SetsWaveLds &L, unsigned n, const char
   fq_lds_wave_sync();
 }
 
+// bitmap index of a carried state: XO = (state - size) * 2 (sequence kernels), else the state itself
+template <bool XO>
+__device__ __forceinline__ unsigned sets_idx(unsigned v, unsigned size) { return XO ? v >> 1 : v - size; }
+
 // merge of equal states among the n classes of L.list; returns the new class count.  Skipped
 // (list untouched) when it would not lower the number of gathers per step.
-__device__ __forceinline__ unsigned sets_merge(SetsWaveLds &L, unsigned n, unsigned n1, unsigned nw) {
+template <bool XO>
+__device__ __forceinline__ unsigned sets_merge(SetsWaveLds &L, unsigned n, unsigned n1, unsigned nw, unsigned size) {
   const unsigned lane = fq_lane();
   sets_clear(L);
   for (unsigned i = lane; i < n; i += 64) {
-    const unsigned xi = (unsigned)L.list[i] >> 1;
+    const unsigned xi = sets_idx<XO>(L.list[i], size);
     atomicOr(&L.bm[xi >> 5], 1u << (xi & 31u));
   }
   fq_lds_wave_sync();
@@ -645,7 +549,7 @@ __device__ __forceinline__ unsigned sets_merge(SetsWaveLds &L, unsigned n, unsig
   for (unsigned j = 0; j < SETS_MAX_CLASSES / 64; j++) {
     const unsigned i = lane + 64u * j;
     st[j] = i < n ? (unsigned)L.list[i] : 0u;
-    if (i < n) L.tmp[i] = (uint16_t)sets_rank(L, st[j] >> 1);
+    if (i < n) L.tmp[i] = (uint16_t)sets_rank(L, sets_idx<XO>(st[j], size));
   }
   fq_lds_wave_sync();
 #pragma unroll
@@ -746,7 +650,7 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
           level = 1; n = n1 = nn;
         }
       } else if (n > 64) {
-        n = sets_merge(L, n, n1, nw);
+        n = sets_merge<true>(L, n, n1, nw, size);
       }
     }
     cur = nxt;
@@ -831,6 +735,321 @@ k_seq_emit(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
   }
   if (k == ns - 1) final_state[c] = (uint16_t)(size + (xo >> 1));
   if (fq_lane() == 0) atomicMax(&res->refixed, len);
+}
+
+// ---- generic chains: segments, single-state symbols and segment functions ---------------
+// Works for any table set; used for the quality stream (and for the sequence stream with
+// FQGPU_CHAIN_SEQ_GENERIC).  A symbol with normalised count 1 or -1 owns ONE table cell: every
+// state emits `log` bits and lands on the same state ("reset" symbol), so the state after it is
+// known without knowing anything before it.  The chain of a context is cut into segments of S
+// symbols; a segment that contains a reset symbol is TRANSPARENT, one that does not is OPAQUE.
+//  k_seg_scan    first reset symbol of every segment (one wave per segment, stops at the first
+//                hit); lists the opaque segments
+//  k_seg_walk<1> one lane per transparent segment: from behind its first reset symbol to the end
+//                of the segment; its final state is the entry state of the next segment
+//  k_seg_setfunc one wave per opaque segment: F: entry state -> exit state over collapsing state
+//                sets, as k_seq_setfunc but stepping through the CTable (symbolTT + stateTable)
+//  k_seg_resolve entry states behind opaque segments: x <- F[x] along every run of them
+//  k_seg_walk<2> one lane per segment: the head of a transparent segment (up to and including
+//                its first reset symbol) or a whole opaque segment, from the entry state
+// Every lane walks at most S symbols, whatever the data: a context without reset symbols (binned
+// or constant qualities) costs state-set work instead of one endless serial chain.
+constexpr unsigned SEG_NONE = 0xFFFFFFFFu;
+
+// segment table of one stream (all arrays indexed by the global segment number)
+struct SegArrays {
+  uint32_t *first_reset;  // offset of the first reset symbol inside the segment, or SEG_NONE
+  uint32_t *fidx;         // function slot of an opaque segment
+  uint32_t *olist;        // opaque segments that have a successor, in no particular order
+  uint32_t *n_opaque;     // length of olist
+  uint16_t *entry_state;  // state in front of the first symbol of every segment
+};
+
+template <class M>
+__device__ __forceinline__ unsigned seg_ctx_of(const uint32_t *__restrict__ base, unsigned v) {
+  unsigned lo = 0, hi = M::B - 1;  // last context c with base[c] <= v
+  while (lo < hi) {
+    const unsigned mid = lo + ((hi - lo + 1) >> 1);
+    if (base[mid] <= v) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <class M>
+__global__ void __launch_bounds__(256)
+k_seg_scan(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
+           const unsigned long long *__restrict__ reset_mask, const uint32_t *__restrict__ logs, unsigned S,
+           SegArrays sa) {
+  constexpr unsigned B = M::B;
+  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
+  const unsigned seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= seg_base[B]) return;  // the grid is an upper bound
+  const unsigned lane = fq_lane();
+  const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
+  const unsigned n = ctx_count[c], begin = k * S, end = min(n, begin + S);
+  const unsigned long long mask = reset_mask[c];
+  const uint8_t *sym = sorted_sym + ctx_start[c];
+  unsigned found = SEG_NONE;
+  if (mask != 0ull) {
+    for (unsigned b0 = begin; b0 < end; b0 += 1024) {
+      const unsigned p = b0 + 16 * lane;
+      unsigned hit = 16;
+      if (p < end) {  // the run is padded to 16 bytes: whole-group loads stay inside it
+        const uint4 v = *reinterpret_cast<const uint4 *>(sym + p);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 15; j >= 0; j--) {
+          const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & (unsigned)(M::A - 1);
+          if (p + j < end && ((mask >> s) & 1ull)) hit = (unsigned)j;
+        }
+      }
+      const unsigned long long any = __ballot(hit < 16);
+      if (any) {
+        const unsigned l0 = (unsigned)__ffsll((long long)any) - 1u;
+        found = (b0 - begin) + 16 * l0 + (unsigned)__shfl((int)hit, (int)l0);
+        break;
+      }
+    }
+  }
+  if (lane == 0) {
+    sa.first_reset[seg] = found;
+    if (k == 0) sa.entry_state[seg] = (uint16_t)(1u << logs[c]);  // FSE_initCState
+    const unsigned nseg = seg_base[c + 1] - seg_base[c];
+    unsigned slot = SEG_NONE;
+    if (found == SEG_NONE && k + 1 < nseg) {
+      slot = atomicAdd(sa.n_opaque, 1u);
+      sa.olist[slot] = seg | (k == 0 ? 0x80000000u : 0u);
+    }
+    sa.fidx[seg] = slot;
+  }
+}
+
+// symbols [i, end) of a context's run walked from state x: packed (nb, bits) into out, 16
+// symbols per 16-byte load and two 16-byte stores per aligned group; returns the final state
+template <class M>
+__device__ __forceinline__ unsigned seg_walk_range(const LdsCTable &t, const uint8_t *__restrict__ sym,
+                                                   uint16_t *__restrict__ out, unsigned i, unsigned end, unsigned x) {
+  while (i < end && (i & 15u)) {
+    out[i] = (uint16_t)chain_step(t, x, sym[i] & (unsigned)(M::A - 1));
+    i++;
+  }
+  if (i + 16 <= end) {
+    const uint4 *sym16 = reinterpret_cast<const uint4 *>(sym);
+    uint4 *out16v = reinterpret_cast<uint4 *>(out);
+    uint4 cur = sym16[i >> 4];
+    while (i + 16 <= end) {
+      const uint4 nxt = i + 32 <= end ? sym16[(i >> 4) + 1] : cur;
+      const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+      unsigned o[8];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const unsigned v = chain_step(t, x, (w[j >> 2] >> (8 * (j & 3))) & (unsigned)(M::A - 1));
+        if (j & 1) o[j >> 1] |= v << 16; else o[j >> 1] = v;
+      }
+      out16v[i >> 3] = make_uint4(o[0], o[1], o[2], o[3]);
+      out16v[(i >> 3) + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+      i += 16;
+      cur = nxt;
+    }
+  }
+  while (i < end) {
+    out[i] = (uint16_t)chain_step(t, x, sym[i] & (unsigned)(M::A - 1));
+    i++;
+  }
+  return x;
+}
+
+// PASS 1: lane = transparent segment, from behind its first reset symbol to its end.
+// PASS 2: lane = segment, its head up to and including the first reset symbol (transparent) or
+//         all of it (opaque), from the resolved entry state.
+template <class M, int PASS>
+__global__ void __launch_bounds__(64)
+k_seg_walk(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
+           const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
+           const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state, unsigned S,
+           SegArrays sa, StreamResult *res) {
+  extern __shared__ uint32_t lds[];
+  constexpr unsigned B = M::B;
+  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
+                 *item_base = seg_base + B + 1;
+  const unsigned item = blockIdx.x;
+  if (item >= item_base[B]) return;  // the grid is an upper bound
+  const unsigned c = seg_ctx_of<M>(item_base, item);
+  const unsigned n = ctx_count[c];
+  const unsigned nseg = seg_base[c + 1] - seg_base[c];
+  const unsigned k = (item - item_base[c]) * 64 + fq_lane();
+  const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
+  if (k >= nseg) return;
+  const unsigned seg = seg_base[c] + k;
+  const uint8_t *sym = sorted_sym + ctx_start[c];
+  uint16_t *out = out16 + ctx_start[c];
+  const unsigned begin = k * S, end = min(n, begin + S);
+  const unsigned fr = sa.first_reset[seg];
+  unsigned x, i0, i1;
+  if (PASS == 1) {
+    if (fr == SEG_NONE) return;
+    i0 = begin + fr + 1; i1 = end;
+    x = reset_state(t, sym[begin + fr] & (unsigned)(M::A - 1));
+  } else {
+    i0 = begin; i1 = fr == SEG_NONE ? end : begin + fr + 1;
+    x = sa.entry_state[seg];
+  }
+  x = seg_walk_range<M>(t, sym, out, i0, i1, x);
+  if (PASS == 1 && k + 1 < nseg) sa.entry_state[seg + 1] = (uint16_t)x;
+  if (k == nseg - 1 && (PASS == 1 || fr == SEG_NONE)) final_state[c] = (uint16_t)x;
+  if (PASS == 2 && fq_lane() == 0) atomicMax(&res->refixed, min(S, n));
+}
+
+// n classes (states in L.list) stepped through words [w0, w1) of the segment with the CTable
+template <class M, int MM>
+__device__ __forceinline__ void seg_sets_walk(SetsWaveLds &L, unsigned n, const LdsCTable &t, const uint4 cur,
+                                              unsigned w0, unsigned w1) {
+  const unsigned lane = fq_lane();
+  unsigned y[MM];
+#pragma unroll
+  for (int j = 0; j < MM; j++) {
+    const unsigned i = lane + 64u * j;
+    y[j] = L.list[i < n ? i : n - 1];
+  }
+  for (unsigned w = w0; w < w1; w++) {
+    const unsigned word = sets_word(cur, w);
+    int dfs[4];
+    unsigned dnb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // uniform addresses: LDS broadcasts, ahead of the dependent chain
+      const unsigned s = (word >> (8 * i)) & (unsigned)(M::A - 1);
+      dfs[i] = (int)t.tt[2 * s];
+      dnb[i] = t.tt[2 * s + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j < MM; j++) {
+        const unsigned nb = (y[j] + dnb[i]) >> 16;
+        y[j] = t.state_table[(int)(y[j] >> nb) + dfs[i]];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MM; j++) {
+    const unsigned i = lane + 64u * j;
+    if (i < n) L.list[i] = (uint16_t)y[j];
+  }
+  fq_lds_wave_sync();
+}
+
+// F of one opaque segment; one wave per workgroup, its own copy of the context's CTable
+template <class M, unsigned PER0>
+__global__ void __launch_bounds__(64)
+k_seg_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
+              const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, unsigned S,
+              unsigned fstride, SegArrays sa, uint16_t *__restrict__ fbuf) {
+  extern __shared__ uint32_t lds[];
+  __shared__ SetsWaveLds L;
+  constexpr unsigned B = M::B;
+  if (blockIdx.x >= *sa.n_opaque) return;  // the grid is an upper bound
+  const uint32_t *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
+  const unsigned seg = sa.olist[blockIdx.x] & 0x7FFFFFFFu;
+  const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
+  const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
+  const unsigned log = t.log, size = 1u << log, lane = fq_lane();
+  const unsigned per = max(size >> 6, 1u), nw = max(size >> 5, 1u);
+  const uint4 *gseg = reinterpret_cast<const uint4 *>(sorted_sym + ctx_start[c] + (size_t)k * S);
+  const unsigned nblk = S / SETS_BLOCK, w_end = S / 4;
+
+  unsigned x0[PER0];  // level 0: every state; lane l carries states size + l, size + l + 64, ...
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) x0[j] = size + ((lane + 64u * j) & (size - 1));
+  unsigned level = 0, n = size, n1 = 0;
+  unsigned w = 0, stop = 1;
+  uint4 cur = gseg[lane];
+  for (unsigned blk = 0; blk < nblk; blk++) {
+    const uint4 nxt = blk + 1 < nblk ? gseg[(size_t)(blk + 1) * 64 + lane] : cur;
+    const unsigned wb_end = (blk + 1) * (SETS_BLOCK / 4);
+    while (w < wb_end) {
+      const unsigned w1 = min(stop, wb_end);
+      if (level == 0) {
+        for (; w < w1; w++) {
+          const unsigned word = sets_word(cur, w);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const unsigned s = (word >> (8 * i)) & (unsigned)(M::A - 1);
+            const int dfs = (int)t.tt[2 * s];
+            const unsigned dnb = t.tt[2 * s + 1];
+#pragma unroll
+            for (unsigned j = 0; j < PER0; j++)
+              if (j < per) { const unsigned nb = (x0[j] + dnb) >> 16; x0[j] = t.state_table[(int)(x0[j] >> nb) + dfs]; }
+          }
+        }
+      } else {
+        switch ((n + 63) / 64) {
+          case 1: seg_sets_walk<M, 1>(L, n, t, cur, w, w1); break;
+          case 2: seg_sets_walk<M, 2>(L, n, t, cur, w, w1); break;
+          case 3: seg_sets_walk<M, 3>(L, n, t, cur, w, w1); break;
+          case 4: seg_sets_walk<M, 4>(L, n, t, cur, w, w1); break;
+          case 5: seg_sets_walk<M, 5>(L, n, t, cur, w, w1); break;
+          case 6: seg_sets_walk<M, 6>(L, n, t, cur, w, w1); break;
+          case 7: seg_sets_walk<M, 7>(L, n, t, cur, w, w1); break;
+          default: seg_sets_walk<M, 8>(L, n, t, cur, w, w1); break;
+        }
+        w = w1;
+      }
+      if (w != stop || w >= w_end) continue;
+      stop = stop == 1 ? 4 : stop == 4 ? 12 : stop == 12 ? 32 : stop * 4;
+      if (level == 0) {
+        sets_clear(L);
+#pragma unroll
+        for (unsigned j = 0; j < PER0; j++)
+          if (j < per) { const unsigned xi = x0[j] - size; atomicOr(&L.bm[xi >> 5], 1u << (xi & 31u)); }
+        fq_lds_wave_sync();
+        const unsigned nn = sets_count(L, nw);
+        if (nn <= SETS_MAX_CLASSES) {
+#pragma unroll
+          for (unsigned j = 0; j < PER0; j++)
+            if (j < per) {
+              const unsigned r = sets_rank(L, x0[j] - size);
+              L.list[r] = (uint16_t)x0[j];
+              x0[j] = r;
+            }
+          for (unsigned i = lane; i < nn; i += 64) L.m[i] = (uint16_t)i;
+          fq_lds_wave_sync();
+          level = 1; n = n1 = nn;
+        }
+      } else if (n > 64) {
+        n = sets_merge<false>(L, n, n1, nw, size);
+      }
+    }
+    cur = nxt;
+  }
+  uint16_t *f = fbuf + (size_t)blockIdx.x * fstride;  // F[entry - size] = exit
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) {
+    const unsigned xi = lane + 64u * j;
+    if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
+  }
+}
+
+// Entry states behind opaque segments.  Every other entry state is already there: k_seg_scan
+// stored the initial state of every chain, k_seg_walk<1> the state behind every transparent
+// segment.  One thread per RUN of consecutive opaque segments: x <- F[x], segment after segment.
+template <class M>
+__global__ void __launch_bounds__(256)
+k_seg_resolve(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ logs,
+              const uint16_t *__restrict__ fbuf, unsigned fstride, SegArrays sa) {
+  constexpr unsigned B = M::B;
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *sa.n_opaque) return;  // the grid is an upper bound
+  const unsigned e = sa.olist[i];
+  unsigned seg = e & 0x7FFFFFFFu;
+  // a run starts at the first segment of a chain or behind a transparent segment
+  if (!(e >> 31) && sa.first_reset[seg - 1] == SEG_NONE) return;
+  const uint32_t *seg_base = arrays + B + (B + 1);
+  const unsigned size = 1u << logs[seg_ctx_of<M>(seg_base, seg)];
+  unsigned x = sa.entry_state[seg];
+  for (unsigned slot = i; slot != SEG_NONE; slot = sa.fidx[seg]) {
+    x = fbuf[(size_t)slot * fstride + (x - size)];
+    sa.entry_state[++seg] = (uint16_t)x;
+  }
 }
 
 // ------------------------------------------------------------------ K6: bit offsets and packing
@@ -1035,7 +1254,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   const unsigned n_sym = (unsigned)b->n_bases;
   const unsigned R = (unsigned)b->n_recs;
   const unsigned T = tile_size<M>();
-  const unsigned S = ctx->seg_len;
+  // segment length of the generic chain kernels: whole 1024-symbol blocks
+  const unsigned S = (unsigned)min(((size_t)ctx->seg_len + SETS_BLOCK - 1) / SETS_BLOCK * SETS_BLOCK, (size_t)1 << 30);
   const unsigned n_tiles = (n_sym + T - 1) / T;
   const unsigned n_groups = (n_tiles + GROUP_TILES - 1) / GROUP_TILES;
   const unsigned n_ptiles = (n_sym + PACK_TILE - 1) / PACK_TILE;
@@ -1059,7 +1279,14 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   seq_S = (unsigned)min(((size_t)seq_S + SETS_BLOCK - 1) / SETS_BLOCK * SETS_BLOCK, (size_t)1 << 30);
   const unsigned seq_max_segs = n_sym / seq_S + B + 1;
   const unsigned seq_fstride = 1u << tab.max_log;
-  if (M::STREAM == 0) {
+  // generic chain kernels (quality stream; sequence stream with FQGPU_CHAIN_SEQ_GENERIC)
+  const unsigned gen_max_segs = n_sym / S + B + 1;
+  const unsigned gen_fstride = 1u << tab.max_log;
+  if (!serial_seq) {
+    if ((rc = sc.seg_arrays.reserve((size_t)gen_max_segs * 16 + 64))) return rc;
+    if ((rc = sc.seq_fbuf.reserve(((size_t)n_sym / S + 2) * gen_fstride * 2 + 64))) return rc;
+  }
+  if (serial_seq) {
     if ((rc = sc.seq_plan.reserve((size_t)SEGPLAN_WORDS * 4 + (size_t)seq_max_segs * 2 + 64))) return rc;
     if ((rc = sc.seq_fbuf.reserve((size_t)seq_max_segs * seq_fstride * 2 + 64))) return rc;
   }
@@ -1090,7 +1317,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
                      sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.chains" : (serial_seq ? "seq.setfunc" : "seq.chains"));
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.scan" : (serial_seq ? "seq.setfunc" : "seq.scan"));
   if (serial_seq) {
     uint32_t *plan = sc.seq_plan.as<uint32_t>();
     uint16_t *entry = reinterpret_cast<uint16_t *>(plan + SEGPLAN_WORDS);
@@ -1118,8 +1345,36 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                          entry, final_state, res);
     }
   } else {
-    hipLaunchKernelGGL(k_chains_reset<M>, dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
-                       sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, res);
+    SegArrays sa;
+    sa.first_reset = sc.seg_arrays.as<uint32_t>();
+    sa.fidx = sa.first_reset + gen_max_segs;
+    sa.olist = sa.fidx + gen_max_segs;
+    sa.n_opaque = sa.olist + gen_max_segs;
+    sa.entry_state = reinterpret_cast<uint16_t *>(sa.n_opaque + 4);
+    uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
+    FQ_HIP(hipMemsetAsync(sa.n_opaque, 0, 4, st));
+    hipLaunchKernelGGL(k_seg_scan<M>, dim3((gen_max_segs + 3) / 4), dim3(256), 0, st, sc.sorted_sym.as<uint8_t>(),
+                       arrays, tab.reset_mask, tab.logs, S, sa);
+    FQ_SPAN_END();
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk1" : "seq.walk1");
+    hipLaunchKernelGGL((k_seg_walk<M, 1>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                       sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, sa, res);
+    FQ_SPAN_END();
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.setfunc" : "seq.setfunc");
+    if (tab.max_log <= 11)
+      hipLaunchKernelGGL((k_seg_setfunc<M, 32>), dim3(n_sym / S + 1), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                         arrays, tab.ct, tab.ct_off, S, gen_fstride, sa, fbuf);
+    else
+      hipLaunchKernelGGL((k_seg_setfunc<M, 64>), dim3(n_sym / S + 1), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                         arrays, tab.ct, tab.ct_off, S, gen_fstride, sa, fbuf);
+    FQ_SPAN_END();
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.resolve" : "seq.resolve");
+    hipLaunchKernelGGL(k_seg_resolve<M>, dim3((n_sym / S + 256) / 256), dim3(256), 0, st, arrays, tab.logs, fbuf,
+                       gen_fstride, sa);
+    FQ_SPAN_END();
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk2" : "seq.walk2");
+    hipLaunchKernelGGL((k_seg_walk<M, 2>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                       sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, sa, res);
   }
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.bitcount" : "seq.bitcount");

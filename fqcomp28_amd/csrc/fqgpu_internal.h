@@ -34,6 +34,7 @@ struct DevTables {
   uint32_t *ct_off = nullptr;   // [B] word offset of each CTable
   uint32_t *dt = nullptr;       // DTable pool, zstd word layout per context
   uint32_t *dt_off = nullptr;   // [B]
+  unsigned long long *reset_mask = nullptr;  // [B] bit s set: symbol s has normalised count 1 or -1
   uint16_t *next1 = nullptr;    // sequence stream only: [B][4 << max_log] one-symbol transition tables,
                                 // next[s][x - size] = ((state after coding s in state x) - size) * 2
   uint32_t max_log = 0;
@@ -101,6 +102,7 @@ struct EncScratch {
   DevBuf group_sum;   // u32 [groups][B]
   DevBuf ctx_arrays;  // ctx_count[B], ctx_start[B+1], seg_base[B+1], item_base[B+1]
   DevBuf seg_state;   // u16 final_state[B]
+  DevBuf seg_arrays;  // generic chain kernels: per-segment tables (encode.hip: SegArrays)
   DevBuf seq_plan;    // segment plan of the sequence chains (encode.hip: SEGPLAN_WORDS) + entry states
   DevBuf seq_fbuf;    // u16 [segments][1 << max_log] segment functions F: entry state -> exit state
   DevBuf tile_bits;   // u32 [ptiles]
@@ -127,7 +129,7 @@ struct fqgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;  // uploads, decode
   DevTables tab[2];
-  unsigned seg_len = 1024;       // nominal segment of the reset-cut chain kernel
+  unsigned seg_len = 4096;       // segment of the generic chain kernels
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
   unsigned seq_segment = 0;      // segment length of the sequence chain kernels (0 = default)
   unsigned n_lanes = 4, next_lane = 0;

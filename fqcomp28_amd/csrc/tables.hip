@@ -438,6 +438,19 @@ k_build_seq_next(const uint32_t *__restrict__ ct, const uint32_t *__restrict__ c
   }
 }
 
+// symbols with normalised count 1 or -1 ("reset" symbols of the chain kernels, encode.hip)
+__global__ void __launch_bounds__(256)
+k_reset_masks(const int16_t *__restrict__ norm, unsigned B, unsigned A, unsigned long long *__restrict__ mask) {
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B) return;
+  unsigned long long m = 0;
+  for (unsigned s = 0; s < A; s++) {
+    const int v = norm[(size_t)c * A + s];
+    if (v == 1 || v == -1) m |= 1ull << s;
+  }
+  mask[c] = m;
+}
+
 // t.norm and t.logs are already on the device; allocates and fills everything else
 int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint32_t *err_dev) {
   const unsigned B = (unsigned)n_models;
@@ -465,6 +478,9 @@ int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint3
   else
     hipLaunchKernelGGL((k_build_tables<FQGPU_QUAL_ALPHA, 6>), dim3(B), dim3(64), 0, st, t.norm, t.logs, t.ct_off,
                        t.dt_off, t.ct, t.dt, err_dev);
+  t.reset_mask = fq_dev_alloc<unsigned long long>(B);
+  if (!t.reset_mask) return FQGPU_E_NOMEM;
+  hipLaunchKernelGGL(k_reset_masks, dim3((B + 255) / 256), dim3(256), 0, st, t.norm, B, (unsigned)alpha, t.reset_mask);
   if (alpha == FQGPU_SEQ_ALPHA) {
     const unsigned stride = 4u << t.max_log;
     t.next1 = fq_dev_alloc<uint16_t>((size_t)B * stride + 64);

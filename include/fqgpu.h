@@ -176,9 +176,9 @@ int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint8_t *se
  * summed duration, kernel_calls = number of launches; total_ms = first start to last end. */
 typedef struct {
   float total_ms;
-  float kernel_ms[24];
-  int kernel_calls[24];
-  const char *kernel_name[24];
+  float kernel_ms[32];
+  int kernel_calls[32];
+  const char *kernel_name[32];
   int n_kernels;
 } fqgpu_timing;
 int fqgpu_ctx_enable_timing(fqgpu_ctx *ctx, int on);
