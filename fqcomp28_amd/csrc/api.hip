@@ -290,7 +290,7 @@ extern "C" int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len,
 
 // ------------------------------------------------------------------ handle
 static void free_tables(DevTables &t) {
-  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off, t.next1, t.reset_mask};
+  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off, t.next1, t.next2, t.reset_mask};
   for (void *p : ps) if (p) (void)hipFree(p);
   t = DevTables();
 }

@@ -414,7 +414,9 @@ __device__ __forceinline__ unsigned reset_state(const LdsCTable &t, unsigned sym
 //      packed (nb, bits) of every symbol; 64 segments of a context per wave.
 // All three read the context's one-symbol transition table next[s][x] from LDS (tables.hip
 // builds it once per handle).  Exact by construction: no speculation, nothing to verify.
-constexpr unsigned SETS_WAVES = 8;          // segments (waves) per workgroup in step A
+constexpr unsigned SETS_WAVES = 8;          // segments (waves) per workgroup in step A, one-symbol table
+constexpr unsigned SETS_WAVES2 = 16;        // ... with the 64 KB two-symbol table (one workgroup per CU)
+constexpr unsigned SETS_ROUNDS = 2;         // a workgroup owns WAVES * SETS_ROUNDS segments, handed out to its waves one by one
 constexpr unsigned SETS_MAX_CLASSES = 512;  // above this a segment keeps carrying every state
 constexpr unsigned SETS_BLOCK = 1024;       // symbols per 16-byte-per-lane load; S is a multiple
 
@@ -431,7 +433,7 @@ struct SetsWaveLds {
 constexpr unsigned SEGPLAN_WORDS = 4 * (SeqModel::B + 1);
 
 __global__ void __launch_bounds__(256)
-k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, uint32_t *__restrict__ plan) {
+k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, unsigned wpg, uint32_t *__restrict__ plan) {
   constexpr unsigned B = SeqModel::B;
   __shared__ unsigned s_nseg[B];
   const unsigned c = threadIdx.x;
@@ -441,13 +443,13 @@ k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, uint32_t *__restr
   unsigned fi = 0, fs = 0, sg = 0, ei = 0;
   for (unsigned o = 0; o < c; o++) {
     const unsigned ns = s_nseg[o], nf = ns ? ns - 1 : 0;
-    fi += (nf + SETS_WAVES - 1) / SETS_WAVES; fs += nf; sg += ns; ei += (ns + 63) / 64;
+    fi += (nf + wpg - 1) / wpg; fs += nf; sg += ns; ei += (ns + 63) / 64;
   }
   uint32_t *fitem = plan, *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *eitem = plan + 3 * (B + 1);
   fitem[c] = fi; fseg[c] = fs; seg[c] = sg; eitem[c] = ei;
   if (c == B - 1) {
     const unsigned ns = s_nseg[c], nf = ns ? ns - 1 : 0;
-    fitem[B] = fi + (nf + SETS_WAVES - 1) / SETS_WAVES; fseg[B] = fs + nf; seg[B] = sg + ns; eitem[B] = ei + (ns + 63) / 64;
+    fitem[B] = fi + (nf + wpg - 1) / wpg; fseg[B] = fs + nf; seg[B] = sg + ns; eitem[B] = ei + (ns + 63) / 64;
   }
 }
 
@@ -499,10 +501,31 @@ __device__ __forceinline__ void sets_clear(SetsWaveLds &L) {
   fq_lds_wave_sync();
 }
 
+// byte offsets of the table rows the four symbols of a word select: one row per symbol, or
+// (TWO) one row of the two-symbol table per symbol pair
+template <bool TWO>
+__device__ __forceinline__ void sets_rows(unsigned word, unsigned log, unsigned (&row)[TWO ? 2 : 4]) {
+  if (TWO) {
+    row[0] = ((word & 3u) | ((word >> 6) & 0xCu)) << (log + 1);
+    row[1] = (((word >> 16) & 3u) | ((word >> 22) & 0xCu)) << (log + 1);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) row[i] = ((word >> (8 * i)) & 3u) << (log + 1);
+  }
+}
+
+// two-symbol table: the lane's 16 symbols as eight 16-bit row offsets, two per dword
+__device__ __forceinline__ uint4 sets_pack_rows(const uint4 cur, unsigned log) {
+  auto pk = [&](unsigned w) {
+    return (((w & 3u) | ((w >> 6) & 0xCu)) << (log + 1)) | (((((w >> 16) & 3u) | ((w >> 22) & 0xCu)) << (log + 1)) << 16);
+  };
+  return make_uint4(pk(cur.x), pk(cur.y), pk(cur.z), pk(cur.w));
+}
+
 // n classes (states in L.list) walked through words [w0, w1) of the segment, M per lane
-template <int M>
+template <int M, bool TWO>
 __device__ __forceinline__ void sets_walk(SetsWaveLds &L, unsigned n, const char *tbase, unsigned log,
-                                          const uint4 cur, unsigned w0, unsigned w1) {
+                                          const uint4 cur, const uint4 rows, unsigned w0, unsigned w1) {
   const unsigned lane = fq_lane();
   unsigned y[M];
 #pragma unroll
@@ -510,13 +533,35 @@ __device__ __forceinline__ void sets_walk(SetsWaveLds &L, unsigned n, const char
     const unsigned i = lane + 64u * j;
     y[j] = L.list[i < n ? i : n - 1];  // spare slots shadow the last class
   }
-  for (unsigned w = w0; w < w1; w++) {
-    const unsigned word = sets_word(cur, w);
+  auto step_word = [&](unsigned word) {
+    unsigned row[TWO ? 2 : 4];
+    sets_rows<TWO>(word, log, row);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const unsigned row = ((word >> (8 * i)) & 3u) << (log + 1);
+    for (int i = 0; i < (TWO ? 2 : 4); i++) {
 #pragma unroll
-      for (int j = 0; j < M; j++) y[j] = *reinterpret_cast<const uint16_t *>(tbase + (row + y[j]));
+      for (int j = 0; j < M; j++) y[j] = *reinterpret_cast<const uint16_t *>(tbase + (row[i] + y[j]));
+    }
+  };
+  if ((w0 | w1) & 3u) {  // only the first two ranges of a segment: [0, 1) and [1, 4)
+    for (unsigned w = w0; w < w1; w++) step_word(sets_word(cur, w));
+  } else if (TWO) {  // whole groups of 16 symbols = eight prepared row offsets of lane g
+    for (unsigned g = w0 >> 2; g < (w1 >> 2); g++) {
+      const unsigned gi = g & 63u;
+      const unsigned r[4] = {(unsigned)__builtin_amdgcn_readlane(rows.x, gi), (unsigned)__builtin_amdgcn_readlane(rows.y, gi),
+                             (unsigned)__builtin_amdgcn_readlane(rows.z, gi), (unsigned)__builtin_amdgcn_readlane(rows.w, gi)};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const unsigned row = (i & 1) ? r[i >> 1] >> 16 : r[i >> 1] & 0xFFFFu;
+#pragma unroll
+        for (int j = 0; j < M; j++) y[j] = *reinterpret_cast<const uint16_t *>(tbase + (row + y[j]));
+      }
+    }
+  } else {
+    for (unsigned g = w0 >> 2; g < (w1 >> 2); g++) {
+      const unsigned gi = g & 63u;
+      const unsigned a = __builtin_amdgcn_readlane(cur.x, gi), b = __builtin_amdgcn_readlane(cur.y, gi),
+                     c = __builtin_amdgcn_readlane(cur.z, gi), d = __builtin_amdgcn_readlane(cur.w, gi);
+      step_word(a); step_word(b); step_word(c); step_word(d);
     }
   }
 #pragma unroll
@@ -563,104 +608,114 @@ __device__ __forceinline__ unsigned sets_merge(SetsWaveLds &L, unsigned n, unsig
 }
 
 // Step A.  PER0 = states per lane at the start: 32 covers log <= 11, 64 covers log 12.
-template <unsigned PER0>
-__global__ void __launch_bounds__(SETS_WAVES * 64)
+// TWO: two symbols per gather through the context's 64 KB two-symbol table (log <= 11).
+template <unsigned PER0, bool TWO>
+__global__ void __launch_bounds__((TWO ? SETS_WAVES2 : SETS_WAVES) * 64)
 k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
               const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs,
-              const uint16_t *__restrict__ next1, unsigned next_stride, unsigned S, unsigned fstride,
+              const uint16_t *__restrict__ next, unsigned next_stride, unsigned S, unsigned fstride,
               uint16_t *__restrict__ fbuf) {
-  extern __shared__ uint32_t lds[];  // next[4][size] of this context
-  __shared__ SetsWaveLds wl[SETS_WAVES];
+  constexpr unsigned WAVES = TWO ? SETS_WAVES2 : SETS_WAVES;
+  extern __shared__ uint32_t lds[];  // next[4][size] (TWO: next2[16][size]) of this context
+  __shared__ SetsWaveLds wl[WAVES];
+  __shared__ unsigned s_next;
   constexpr unsigned B = SeqModel::B;
   const uint32_t *fitem = plan, *fseg = plan + (B + 1);
   if (blockIdx.x >= fitem[B]) return;  // the grid is an upper bound
+  if (threadIdx.x == 0) s_next = WAVES;
   const unsigned c = seq_item_ctx(fitem, blockIdx.x);
   const unsigned log = logs[c], size = 1u << log;
-  {  // 4 * size u16 entries, a multiple of 16 bytes
-    const uint4 *src = reinterpret_cast<const uint4 *>(next1 + (size_t)c * next_stride);
+  {  // (4 or 16) * size u16 entries, a multiple of 16 bytes
+    const uint4 *src = reinterpret_cast<const uint4 *>(next + (size_t)c * next_stride);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (unsigned e = threadIdx.x; e < size / 2; e += SETS_WAVES * 64) dst[e] = src[e];
+    for (unsigned e = threadIdx.x; e < (TWO ? 2 * size : size / 2); e += WAVES * 64) dst[e] = src[e];
   }
   __syncthreads();
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
   const unsigned nf = fseg[c + 1] - fseg[c];
-  const unsigned k = (blockIdx.x - fitem[c]) * SETS_WAVES + wave;  // segment k of the chain
-  if (k >= nf) return;
+  // the workgroup's segments [k0, k_end) of the chain go to whichever wave is free
+  const unsigned k0 = (blockIdx.x - fitem[c]) * (WAVES * SETS_ROUNDS), k_end = min(k0 + WAVES * SETS_ROUNDS, nf);
   SetsWaveLds &L = wl[wave];
   const char *tbase = reinterpret_cast<const char *>(lds);
   const unsigned per = max(size >> 6, 1u), nw = max(size >> 5, 1u);
-  const uint4 *gseg = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)k * S);
   const unsigned nblk = S / SETS_BLOCK, w_end = S / 4;
+  for (unsigned k = k0 + wave; k < k_end;) {
+    const uint4 *gseg = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)k * S);
 
-  // level 0: every state; lane l carries states l, l + 64, ...
-  unsigned x0[PER0];
+    // level 0: every state; lane l carries states l, l + 64, ...
+    unsigned x0[PER0];
 #pragma unroll
-  for (unsigned j = 0; j < PER0; j++) x0[j] = ((lane + 64u * j) & (size - 1)) * 2u;
-  unsigned level = 0, n = size, n1 = 0;
-  unsigned w = 0, stop = 1;  // merge points after 4, 16, 48, 128, 512, 2048, 8192, ... symbols
-  uint4 cur = gseg[lane];
-  for (unsigned blk = 0; blk < nblk; blk++) {
-    const uint4 nxt = blk + 1 < nblk ? gseg[(size_t)(blk + 1) * 64 + lane] : cur;  // lands while cur is walked
-    const unsigned wb_end = (blk + 1) * (SETS_BLOCK / 4);
-    while (w < wb_end) {
-      const unsigned w1 = min(stop, wb_end);
-      if (level == 0) {
-        for (; w < w1; w++) {
-          const unsigned word = sets_word(cur, w);
+    for (unsigned j = 0; j < PER0; j++) x0[j] = ((lane + 64u * j) & (size - 1)) * 2u;
+    unsigned level = 0, n = size, n1 = 0;
+    unsigned w = 0, stop = 1;  // merge points after 4, 16, 48, 128, 512, 2048, 8192, ... symbols
+    uint4 cur = gseg[lane];
+    for (unsigned blk = 0; blk < nblk; blk++) {
+      const uint4 nxt = blk + 1 < nblk ? gseg[(size_t)(blk + 1) * 64 + lane] : cur;  // lands while cur is walked
+      const unsigned wb_end = (blk + 1) * (SETS_BLOCK / 4);
+      const uint4 rows = TWO ? sets_pack_rows(cur, log) : cur;
+      while (w < wb_end) {
+        const unsigned w1 = min(stop, wb_end);
+        if (level == 0) {
+          for (; w < w1; w++) {
+            unsigned row[TWO ? 2 : 4];
+            sets_rows<TWO>(sets_word(cur, w), log, row);
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const unsigned row = ((word >> (8 * i)) & 3u) << (log + 1);
+            for (int i = 0; i < (TWO ? 2 : 4); i++) {
 #pragma unroll
-            for (unsigned j = 0; j < PER0; j++)
-              if (j < per) x0[j] = *reinterpret_cast<const uint16_t *>(tbase + (row + x0[j]));
+              for (unsigned j = 0; j < PER0; j++)
+                if (j < per) x0[j] = *reinterpret_cast<const uint16_t *>(tbase + (row[i] + x0[j]));
+            }
           }
+        } else {
+          switch ((n + 63) / 64) {
+            case 1: sets_walk<1, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+            case 2: sets_walk<2, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+            case 3: sets_walk<3, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+            case 4: sets_walk<4, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+            case 5: sets_walk<5, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+            case 6: sets_walk<6, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+            case 7: sets_walk<7, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+            default: sets_walk<8, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+          }
+          w = w1;
         }
-      } else {
-        switch ((n + 63) / 64) {
-          case 1: sets_walk<1>(L, n, tbase, log, cur, w, w1); break;
-          case 2: sets_walk<2>(L, n, tbase, log, cur, w, w1); break;
-          case 3: sets_walk<3>(L, n, tbase, log, cur, w, w1); break;
-          case 4: sets_walk<4>(L, n, tbase, log, cur, w, w1); break;
-          case 5: sets_walk<5>(L, n, tbase, log, cur, w, w1); break;
-          case 6: sets_walk<6>(L, n, tbase, log, cur, w, w1); break;
-          case 7: sets_walk<7>(L, n, tbase, log, cur, w, w1); break;
-          default: sets_walk<8>(L, n, tbase, log, cur, w, w1); break;
-        }
-        w = w1;
-      }
-      if (w != stop || w >= w_end) continue;
-      stop = stop == 1 ? 4 : stop == 4 ? 12 : stop == 12 ? 32 : stop * 4;
-      if (level == 0) {
-        sets_clear(L);
-#pragma unroll
-        for (unsigned j = 0; j < PER0; j++)
-          if (j < per) { const unsigned xi = x0[j] >> 1; atomicOr(&L.bm[xi >> 5], 1u << (xi & 31u)); }
-        fq_lds_wave_sync();
-        const unsigned nn = sets_count(L, nw);
-        if (nn <= SETS_MAX_CLASSES) {  // from here on only the distinct states are carried
+        if (w != stop || w >= w_end) continue;
+        stop = stop == 1 ? 4 : stop == 4 ? 12 : stop == 12 ? 32 : stop * 4;
+        if (level == 0) {
+          sets_clear(L);
 #pragma unroll
           for (unsigned j = 0; j < PER0; j++)
-            if (j < per) {
-              const unsigned r = sets_rank(L, x0[j] >> 1);
-              L.list[r] = (uint16_t)x0[j];
-              x0[j] = r;  // class of entry state lane + 64 j
-            }
-          for (unsigned i = lane; i < nn; i += 64) L.m[i] = (uint16_t)i;
+            if (j < per) { const unsigned xi = x0[j] >> 1; atomicOr(&L.bm[xi >> 5], 1u << (xi & 31u)); }
           fq_lds_wave_sync();
-          level = 1; n = n1 = nn;
-        }
-      } else if (n > 64) {
-        n = sets_merge<true>(L, n, n1, nw, size);
-      }
-    }
-    cur = nxt;
-  }
-  // F[entry] = exit, both as (state - size) * 2
-  uint16_t *f = fbuf + (size_t)(fseg[c] + k) * fstride;
+          const unsigned nn = sets_count(L, nw);
+          if (nn <= SETS_MAX_CLASSES) {  // from here on only the distinct states are carried
 #pragma unroll
-  for (unsigned j = 0; j < PER0; j++) {
-    const unsigned xi = lane + 64u * j;
-    if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
+            for (unsigned j = 0; j < PER0; j++)
+              if (j < per) {
+                const unsigned r = sets_rank(L, x0[j] >> 1);
+                L.list[r] = (uint16_t)x0[j];
+                x0[j] = r;  // class of entry state lane + 64 j
+              }
+            for (unsigned i = lane; i < nn; i += 64) L.m[i] = (uint16_t)i;
+            fq_lds_wave_sync();
+            level = 1; n = n1 = nn;
+          }
+        } else if (n > 64) {
+          n = sets_merge<true>(L, n, n1, nw, size);
+        }
+      }
+      cur = nxt;
+    }
+    // F[entry] = exit, both as (state - size) * 2
+    uint16_t *f = fbuf + (size_t)(fseg[c] + k) * fstride;
+#pragma unroll
+    for (unsigned j = 0; j < PER0; j++) {
+      const unsigned xi = lane + 64u * j;
+      if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
+    }
+    unsigned nk = 0;
+    if (lane == 0) nk = atomicAdd(&s_next, 1u);
+    k = k0 + (unsigned)__builtin_amdgcn_readfirstlane(nk);
   }
 }
 
@@ -1323,16 +1378,18 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     uint16_t *entry = reinterpret_cast<uint16_t *>(plan + SEGPLAN_WORDS);
     uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
     const unsigned next_stride = 4u << tab.max_log;
-    const unsigned max_fitems = seq_max_segs / SETS_WAVES + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
+    const bool two = tab.next2 != nullptr;  // two-symbol tables exist up to log 11
+    const unsigned wpg = two ? SETS_WAVES2 : SETS_WAVES;
+    const unsigned max_fitems = seq_max_segs / (wpg * SETS_ROUNDS) + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
     static const bool dbg_skip = getenv("FQGPU_DEBUG_SKIP_SEQ_CHAIN") != nullptr;  // timing experiment only: wrong output
-    hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, plan);
+    hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, wpg * SETS_ROUNDS, plan);
     if (!dbg_skip) {
-      if (tab.max_log <= 11)
-        hipLaunchKernelGGL(k_seq_setfunc<32>, dim3(max_fitems), dim3(SETS_WAVES * 64), 8u << tab.max_log, st,
-                           sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1, next_stride, seq_S,
+      if (two)
+        hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(max_fitems), dim3(SETS_WAVES2 * 64), 32u << tab.max_log, st,
+                           sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2, 4 * next_stride, seq_S,
                            seq_fstride, fbuf);
       else
-        hipLaunchKernelGGL(k_seq_setfunc<64>, dim3(max_fitems), dim3(SETS_WAVES * 64), 8u << tab.max_log, st,
+        hipLaunchKernelGGL((k_seq_setfunc<64, false>), dim3(max_fitems), dim3(SETS_WAVES * 64), 8u << tab.max_log, st,
                            sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1, next_stride, seq_S,
                            seq_fstride, fbuf);
       FQ_SPAN_END();
@@ -1430,8 +1487,10 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
 
   FQ_HIP(hipEventRecord(lane.ev_fork, lane.st_seq));
   FQ_HIP(hipStreamWaitEvent(lane.st_qual, lane.ev_fork, 0));
-  if ((rc = encode_stream<QualModel>(ctx, lane, lane.st_qual, b, rec_start, b->qual, b->qual_cap))) return rc;
-  if ((rc = encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, b->seq, b->seq_cap))) return rc;
+  // timing experiments only (wrong output): one stream at a time
+  static const bool dbg_no_qual = getenv("FQGPU_DEBUG_SKIP_QUAL") != nullptr, dbg_no_seq = getenv("FQGPU_DEBUG_SKIP_SEQ") != nullptr;
+  if (!dbg_no_qual && (rc = encode_stream<QualModel>(ctx, lane, lane.st_qual, b, rec_start, b->qual, b->qual_cap))) return rc;
+  if (!dbg_no_seq && (rc = encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, b->seq, b->seq_cap))) return rc;
   FQ_HIP(hipEventRecord(lane.ev_join, lane.st_qual));
   FQ_HIP(hipStreamWaitEvent(lane.st_seq, lane.ev_join, 0));
 

@@ -37,6 +37,8 @@ struct DevTables {
   unsigned long long *reset_mask = nullptr;  // [B] bit s set: symbol s has normalised count 1 or -1
   uint16_t *next1 = nullptr;    // sequence stream only: [B][4 << max_log] one-symbol transition tables,
                                 // next[s][x - size] = ((state after coding s in state x) - size) * 2
+  uint16_t *next2 = nullptr;    // sequence stream, max_log <= 11: [B][16 << max_log] two-symbol tables,
+                                // next2[s1 | s2 << 2][x - size] = next[s2][next[s1][x - size]]
   uint32_t max_log = 0;
   size_t ct_words = 0, dt_words = 0;
 };

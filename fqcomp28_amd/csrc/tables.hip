@@ -438,6 +438,19 @@ k_build_seq_next(const uint32_t *__restrict__ ct, const uint32_t *__restrict__ c
   }
 }
 
+// two symbols per lookup: next2[s1 | s2 << 2][xi] = next[s2][next[s1][xi]] (same pre-scaling)
+__global__ void __launch_bounds__(256)
+k_build_seq_next2(const uint32_t *__restrict__ logs, const uint16_t *__restrict__ next1, unsigned stride1,
+                  unsigned stride2, uint16_t *__restrict__ next2) {
+  const unsigned log = logs[blockIdx.x], size = 1u << log;
+  const uint16_t *n1 = next1 + (size_t)blockIdx.x * stride1;
+  uint16_t *n2 = next2 + (size_t)blockIdx.x * stride2;
+  for (unsigned e = threadIdx.x; e < 16 * size; e += 256) {
+    const unsigned xi = e & (size - 1), pc = e >> log, s1 = pc & 3u, s2 = pc >> 2;
+    n2[e] = n1[(s2 << log) + ((unsigned)n1[(s1 << log) + xi] >> 1)];
+  }
+}
+
 // symbols with normalised count 1 or -1 ("reset" symbols of the chain kernels, encode.hip)
 __global__ void __launch_bounds__(256)
 k_reset_masks(const int16_t *__restrict__ norm, unsigned B, unsigned A, unsigned long long *__restrict__ mask) {
@@ -486,6 +499,11 @@ int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint3
     t.next1 = fq_dev_alloc<uint16_t>((size_t)B * stride + 64);
     if (!t.next1) return FQGPU_E_NOMEM;
     hipLaunchKernelGGL(k_build_seq_next, dim3(B), dim3(256), 0, st, t.ct, t.ct_off, stride, t.next1);
+    if (t.max_log <= 11) {
+      t.next2 = fq_dev_alloc<uint16_t>((size_t)B * 4 * stride + 64);
+      if (!t.next2) return FQGPU_E_NOMEM;
+      hipLaunchKernelGGL(k_build_seq_next2, dim3(B), dim3(256), 0, st, t.logs, t.next1, stride, 4 * stride, t.next2);
+    }
   }
   FQ_HIP(hipGetLastError());
   return FQGPU_OK;
