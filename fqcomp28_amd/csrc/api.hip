@@ -333,6 +333,10 @@ extern "C" int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual
   fqgpu_ctx *ctx = new (std::nothrow) fqgpu_ctx();
   if (!ctx) return FQGPU_E_NOMEM;
   ctx->device = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = (unsigned)cus;
+  }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return FQGPU_E_HIP;

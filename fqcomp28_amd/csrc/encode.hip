@@ -430,7 +430,7 @@ struct SetsWaveLds {
 
 // plan[]: fitem_base[B+1] (step A workgroups before every context) | fseg_base[B+1] (functions
 // before every context) | seg_base[B+1] (segments) | eitem_base[B+1] (step C waves)
-constexpr unsigned SEGPLAN_WORDS = 4 * (SeqModel::B + 1);
+constexpr unsigned SEGPLAN_WORDS = 4 * (SeqModel::B + 1) + 4;  // + the work counter of step A
 
 __global__ void __launch_bounds__(256)
 k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, unsigned wpg, uint32_t *__restrict__ plan) {
@@ -447,6 +447,7 @@ k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, unsigned wpg, uin
   }
   uint32_t *fitem = plan, *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *eitem = plan + 3 * (B + 1);
   fitem[c] = fi; fseg[c] = fs; seg[c] = sg; eitem[c] = ei;
+  if (c == 0) plan[4 * (B + 1)] = 0;  // step A's work counter
   if (c == B - 1) {
     const unsigned ns = s_nseg[c], nf = ns ? ns - 1 : 0;
     fitem[B] = fi + (nf + wpg - 1) / wpg; fseg[B] = fs + nf; seg[B] = sg + ns; eitem[B] = ei + (ns + 63) / 64;
@@ -614,108 +615,119 @@ __global__ void __launch_bounds__((TWO ? SETS_WAVES2 : SETS_WAVES) * 64)
 k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
               const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs,
               const uint16_t *__restrict__ next, unsigned next_stride, unsigned S, unsigned fstride,
-              uint16_t *__restrict__ fbuf) {
+              uint16_t *__restrict__ fbuf, unsigned *__restrict__ work_counter) {
   constexpr unsigned WAVES = TWO ? SETS_WAVES2 : SETS_WAVES;
   extern __shared__ uint32_t lds[];  // next[4][size] (TWO: next2[16][size]) of this context
   __shared__ SetsWaveLds wl[WAVES];
-  __shared__ unsigned s_next;
+  __shared__ unsigned s_next, s_item;
   constexpr unsigned B = SeqModel::B;
   const uint32_t *fitem = plan, *fseg = plan + (B + 1);
-  if (blockIdx.x >= fitem[B]) return;  // the grid is an upper bound
-  if (threadIdx.x == 0) s_next = WAVES;
-  const unsigned c = seq_item_ctx(fitem, blockIdx.x);
-  const unsigned log = logs[c], size = 1u << log;
-  {  // (4 or 16) * size u16 entries, a multiple of 16 bytes
-    const uint4 *src = reinterpret_cast<const uint4 *>(next + (size_t)c * next_stride);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (unsigned e = threadIdx.x; e < (TWO ? 2 * size : size / 2); e += WAVES * 64) dst[e] = src[e];
-  }
-  __syncthreads();
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
-  const unsigned nf = fseg[c + 1] - fseg[c];
-  // the workgroup's segments [k0, k_end) of the chain go to whichever wave is free
-  const unsigned k0 = (blockIdx.x - fitem[c]) * (WAVES * SETS_ROUNDS), k_end = min(k0 + WAVES * SETS_ROUNDS, nf);
   SetsWaveLds &L = wl[wave];
   const char *tbase = reinterpret_cast<const char *>(lds);
-  const unsigned per = max(size >> 6, 1u), nw = max(size >> 5, 1u);
   const unsigned nblk = S / SETS_BLOCK, w_end = S / 4;
-  for (unsigned k = k0 + wave; k < k_end;) {
-    const uint4 *gseg = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)k * S);
+  const unsigned n_items = fitem[B];
+  unsigned loaded = 0xFFFFFFFFu;  // context whose table is in LDS
+  // Persistent workgroups (one per CU, 125 KB of LDS with the two-symbol table): items are
+  // (context, group of WAVES * SETS_ROUNDS segments), taken from a global counter, so a
+  // workgroup that has found a CU keeps it until the work is gone.
+  for (;;) {
+    __syncthreads();  // every wave is done with the previous item's table and queue
+    if (threadIdx.x == 0) { s_item = atomicAdd(work_counter, 1u); s_next = WAVES; }
+    __syncthreads();
+    const unsigned item = s_item;
+    if (item >= n_items) break;
+    const unsigned c = seq_item_ctx(fitem, item);
+    const unsigned log = logs[c], size = 1u << log;
+    if (c != loaded) {  // (4 or 16) * size u16 entries, a multiple of 16 bytes
+      const uint4 *src = reinterpret_cast<const uint4 *>(next + (size_t)c * next_stride);
+      uint4 *dst = reinterpret_cast<uint4 *>(lds);
+      for (unsigned e = threadIdx.x; e < (TWO ? 2 * size : size / 2); e += WAVES * 64) dst[e] = src[e];
+      loaded = c;
+      __syncthreads();
+    }
+    const unsigned nf = fseg[c + 1] - fseg[c];
+    // the item's segments [k0, k_end) of the chain go to whichever wave is free
+    const unsigned k0 = (item - fitem[c]) * (WAVES * SETS_ROUNDS), k_end = min(k0 + WAVES * SETS_ROUNDS, nf);
+    const unsigned per = max(size >> 6, 1u), nw = max(size >> 5, 1u);
+    for (unsigned k = k0 + wave; k < k_end;) {
+      const uint4 *gseg = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)k * S);
 
-    // level 0: every state; lane l carries states l, l + 64, ...
-    unsigned x0[PER0];
+      // level 0: every state; lane l carries states l, l + 64, ...
+      unsigned x0[PER0];
 #pragma unroll
-    for (unsigned j = 0; j < PER0; j++) x0[j] = ((lane + 64u * j) & (size - 1)) * 2u;
-    unsigned level = 0, n = size, n1 = 0;
-    unsigned w = 0, stop = 1;  // merge points after 4, 16, 48, 128, 512, 2048, 8192, ... symbols
-    uint4 cur = gseg[lane];
-    for (unsigned blk = 0; blk < nblk; blk++) {
-      const uint4 nxt = blk + 1 < nblk ? gseg[(size_t)(blk + 1) * 64 + lane] : cur;  // lands while cur is walked
-      const unsigned wb_end = (blk + 1) * (SETS_BLOCK / 4);
-      const uint4 rows = TWO ? sets_pack_rows(cur, log) : cur;
-      while (w < wb_end) {
-        const unsigned w1 = min(stop, wb_end);
-        if (level == 0) {
-          for (; w < w1; w++) {
-            unsigned row[TWO ? 2 : 4];
-            sets_rows<TWO>(sets_word(cur, w), log, row);
+      for (unsigned j = 0; j < PER0; j++) x0[j] = ((lane + 64u * j) & (size - 1)) * 2u;
+      unsigned level = 0, n = size, n1 = 0;
+      unsigned w = 0, stop = 1;  // merge points after 4, 16, 48, 128, 512, 2048, 8192, ... symbols
+      uint4 cur = gseg[lane];
+      for (unsigned blk = 0; blk < nblk; blk++) {
+        const uint4 nxt = blk + 1 < nblk ? gseg[(size_t)(blk + 1) * 64 + lane] : cur;  // lands while cur is walked
+        const unsigned wb_end = (blk + 1) * (SETS_BLOCK / 4);
+        const uint4 rows = TWO ? sets_pack_rows(cur, log) : cur;
+        while (w < wb_end) {
+          const unsigned w1 = min(stop, wb_end);
+          if (level == 0) {
+            for (; w < w1; w++) {
+              unsigned row[TWO ? 2 : 4];
+              sets_rows<TWO>(sets_word(cur, w), log, row);
 #pragma unroll
-            for (int i = 0; i < (TWO ? 2 : 4); i++) {
+              for (int i = 0; i < (TWO ? 2 : 4); i++) {
 #pragma unroll
-              for (unsigned j = 0; j < PER0; j++)
-                if (j < per) x0[j] = *reinterpret_cast<const uint16_t *>(tbase + (row[i] + x0[j]));
+                for (unsigned j = 0; j < PER0; j++)
+                  if (j < per) x0[j] = *reinterpret_cast<const uint16_t *>(tbase + (row[i] + x0[j]));
+              }
             }
+          } else {
+            switch ((n + 63) / 64) {
+              case 1: sets_walk<1, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+              case 2: sets_walk<2, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+              case 3: sets_walk<3, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+              case 4: sets_walk<4, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+              case 5: sets_walk<5, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+              case 6: sets_walk<6, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+              case 7: sets_walk<7, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+              default: sets_walk<8, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
+            }
+            w = w1;
           }
-        } else {
-          switch ((n + 63) / 64) {
-            case 1: sets_walk<1, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
-            case 2: sets_walk<2, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
-            case 3: sets_walk<3, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
-            case 4: sets_walk<4, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
-            case 5: sets_walk<5, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
-            case 6: sets_walk<6, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
-            case 7: sets_walk<7, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
-            default: sets_walk<8, TWO>(L, n, tbase, log, cur, rows, w, w1); break;
-          }
-          w = w1;
-        }
-        if (w != stop || w >= w_end) continue;
-        stop = stop == 1 ? 4 : stop == 4 ? 12 : stop == 12 ? 32 : stop * 4;
-        if (level == 0) {
-          sets_clear(L);
-#pragma unroll
-          for (unsigned j = 0; j < PER0; j++)
-            if (j < per) { const unsigned xi = x0[j] >> 1; atomicOr(&L.bm[xi >> 5], 1u << (xi & 31u)); }
-          fq_lds_wave_sync();
-          const unsigned nn = sets_count(L, nw);
-          if (nn <= SETS_MAX_CLASSES) {  // from here on only the distinct states are carried
+          if (w != stop || w >= w_end) continue;
+          stop = stop == 1 ? 4 : stop == 4 ? 12 : stop == 12 ? 32 : stop * 4;
+          if (level == 0) {
+            sets_clear(L);
 #pragma unroll
             for (unsigned j = 0; j < PER0; j++)
-              if (j < per) {
-                const unsigned r = sets_rank(L, x0[j] >> 1);
-                L.list[r] = (uint16_t)x0[j];
-                x0[j] = r;  // class of entry state lane + 64 j
-              }
-            for (unsigned i = lane; i < nn; i += 64) L.m[i] = (uint16_t)i;
+              if (j < per) { const unsigned xi = x0[j] >> 1; atomicOr(&L.bm[xi >> 5], 1u << (xi & 31u)); }
             fq_lds_wave_sync();
-            level = 1; n = n1 = nn;
-          }
-        } else if (n > 64) {
-          n = sets_merge<true>(L, n, n1, nw, size);
-        }
-      }
-      cur = nxt;
-    }
-    // F[entry] = exit, both as (state - size) * 2
-    uint16_t *f = fbuf + (size_t)(fseg[c] + k) * fstride;
+            const unsigned nn = sets_count(L, nw);
+            if (nn <= SETS_MAX_CLASSES) {  // from here on only the distinct states are carried
 #pragma unroll
-    for (unsigned j = 0; j < PER0; j++) {
-      const unsigned xi = lane + 64u * j;
-      if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
+              for (unsigned j = 0; j < PER0; j++)
+                if (j < per) {
+                  const unsigned r = sets_rank(L, x0[j] >> 1);
+                  L.list[r] = (uint16_t)x0[j];
+                  x0[j] = r;  // class of entry state lane + 64 j
+                }
+              for (unsigned i = lane; i < nn; i += 64) L.m[i] = (uint16_t)i;
+              fq_lds_wave_sync();
+              level = 1; n = n1 = nn;
+            }
+          } else if (n > 64) {
+            n = sets_merge<true>(L, n, n1, nw, size);
+          }
+        }
+        cur = nxt;
+      }
+      // F[entry] = exit, both as (state - size) * 2
+      uint16_t *f = fbuf + (size_t)(fseg[c] + k) * fstride;
+#pragma unroll
+      for (unsigned j = 0; j < PER0; j++) {
+        const unsigned xi = lane + 64u * j;
+        if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
+      }
+      unsigned nk = 0;
+      if (lane == 0) nk = atomicAdd(&s_next, 1u);
+      k = k0 + (unsigned)__builtin_amdgcn_readfirstlane(nk);
     }
-    unsigned nk = 0;
-    if (lane == 0) nk = atomicAdd(&s_next, 1u);
-    k = k0 + (unsigned)__builtin_amdgcn_readfirstlane(nk);
   }
 }
 
@@ -1385,13 +1397,13 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, wpg * SETS_ROUNDS, plan);
     if (!dbg_skip) {
       if (two)
-        hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(max_fitems), dim3(SETS_WAVES2 * 64), 32u << tab.max_log, st,
-                           sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2, 4 * next_stride, seq_S,
-                           seq_fstride, fbuf);
+        hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(min(max_fitems, ctx->n_cus)), dim3(SETS_WAVES2 * 64),
+                           32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2,
+                           4 * next_stride, seq_S, seq_fstride, fbuf, plan + 4 * (B + 1));
       else
-        hipLaunchKernelGGL((k_seq_setfunc<64, false>), dim3(max_fitems), dim3(SETS_WAVES * 64), 8u << tab.max_log, st,
-                           sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1, next_stride, seq_S,
-                           seq_fstride, fbuf);
+        hipLaunchKernelGGL((k_seq_setfunc<64, false>), dim3(min(max_fitems, 2 * ctx->n_cus)), dim3(SETS_WAVES * 64),
+                           8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1,
+                           next_stride, seq_S, seq_fstride, fbuf, plan + 4 * (B + 1));
       FQ_SPAN_END();
       FQ_SPAN_BEGIN("seq.resolve");
       hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, entry);

@@ -134,6 +134,7 @@ struct fqgpu_ctx {
   unsigned seg_len = 4096;       // segment of the generic chain kernels
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
   unsigned seq_segment = 0;      // segment length of the sequence chain kernels (0 = default)
+  unsigned n_cus = 256;          // compute units of the device (grid of the persistent kernels)
   unsigned n_lanes = 4, next_lane = 0;
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch
