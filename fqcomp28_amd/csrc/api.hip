@@ -341,7 +341,9 @@ extern "C" int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual
     delete ctx;
     return FQGPU_E_HIP;
   }
-  rc = upload_tables(ctx, 0, seq_ft);
+  rc = fq_probe_lds_atomic_order(ctx->stream, &ctx->lds_atomics_ordered);
+  if (getenv("FQGPU_NO_LDS_ATOMIC_RANK")) ctx->lds_atomics_ordered = false;  // force the ballot kernel
+  if (!rc) rc = upload_tables(ctx, 0, seq_ft);
   if (!rc) rc = upload_tables(ctx, 1, qual_ft);
   if (rc) { fqgpu_ctx_destroy(ctx); return rc; }
   *out = ctx;

@@ -284,11 +284,17 @@ k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__
 // costs two thirds of the occupancy and the loop is VALU-bound on the ballot match, not on stores.)
 constexpr unsigned SC_BATCH = 2048;
 
-template <class M>
+// ORDERED: the rank comes from one LDS atomic per lane instead of the ballot match.  Same-address
+// LDS atomics of ONE wave instruction take effect in lane order on gfx950 -- measured
+// (tools/lds_atomic_order.hip: 0 mismatches in 7.9e9 lane-ops, packed and plain counters), not
+// documented, so every handle re-verifies it at creation (fq_probe_lds_atomic_order) and falls
+// back to the ballot kernel otherwise.  REL packs two 16-bit cursors per word: a cursor reaches
+// 65536 only with the last symbol of a tile that holds nothing but that context.
+template <class M, bool ORDERED>
 __global__ void __launch_bounds__(64)
 k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
           const uint32_t *__restrict__ tile_base, uint8_t *__restrict__ sorted_sym,
-          uint32_t *__restrict__ slot_of) {
+          uint32_t *__restrict__ slot_of, int dbg_no_sym) {
   constexpr unsigned B = M::B;
   // REL (many contexts): 16-bit cursors relative to the tile's base (a tile has at most 65536
   // symbols), 16 KB instead of 32 KB of LDS; the base is added from the (L2-resident) tile_base
@@ -296,6 +302,7 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
   constexpr bool REL = B > 1024;
   using cur_t = typename std::conditional<REL, uint16_t, uint32_t>::type;
   __shared__ cur_t cursor[B];  // REL: rank inside the tile, else global slot
+  uint32_t *cursor32 = reinterpret_cast<uint32_t *>(cursor);
   __shared__ uint4 kbatch4[SC_BATCH / 4], sbatch4[REL ? SC_BATCH / 8 : SC_BATCH / 4];
   uint32_t *kbatch = reinterpret_cast<uint32_t *>(kbatch4), *sbatch = reinterpret_cast<uint32_t *>(sbatch4);
   uint16_t *rbatch = reinterpret_cast<uint16_t *>(sbatch4);
@@ -312,6 +319,17 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
 #pragma unroll
     for (unsigned i = 0; i < SC_BATCH / 4 / 64; i++) kbatch4[i * 64 + lane] = gk[i * 64 + lane];
     fq_lds_wave_sync();
+    if (ORDERED) {
+      for (unsigned cb = 0; cb < nb; cb += 64) {  // no global memory operation in here
+        const unsigned i = cb + lane;
+        if (i < nb) {
+          const unsigned ctx = kbatch[i] & 0xFFFFu;
+          if (REL) rbatch[i] = (uint16_t)(atomicAdd(&cursor32[ctx >> 1], 1u << (16 * (ctx & 1u))) >> (16 * (ctx & 1u)));
+          else sbatch[i] = atomicAdd(&cursor32[ctx], 1u);
+        }
+      }
+      fq_lds_wave_sync();
+    } else
     for (unsigned cb = 0; cb < nb; cb += 64) {  // no global memory operation in here
       const unsigned i = cb + lane;
       const bool valid = i < nb;
@@ -337,7 +355,7 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
 #pragma unroll
         for (unsigned j = 0; j < SC_BATCH / 64; j++) {
           slot_of[b0 + j * 64 + lane] = slots[j];
-          sorted_sym[slots[j]] = (uint8_t)(kbatch[j * 64 + lane] >> 16);
+          if (!dbg_no_sym) sorted_sym[slots[j]] = (uint8_t)(kbatch[j * 64 + lane] >> 16);
         }
       } else {
         for (unsigned i = lane; i < nb; i += 64) {
@@ -355,7 +373,7 @@ k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
       } else {
         for (unsigned i = lane; i < nb; i += 64) slot_of[b0 + i] = sbatch[i];
       }
-      for (unsigned i = lane; i < nb; i += 64) sorted_sym[sbatch[i]] = (uint8_t)(kbatch[i] >> 16);
+      if (!dbg_no_sym) for (unsigned i = lane; i < nb; i += 64) sorted_sym[sbatch[i]] = (uint8_t)(kbatch[i] >> 16);
     }
     fq_lds_wave_sync();
   }
@@ -1312,6 +1330,13 @@ k_epilogue(const uint32_t *__restrict__ arrays, const uint16_t *__restrict__ fin
 #define FQ_SPAN_BEGIN(name) fq_timer_span_begin(ctx, name, st)
 #define FQ_SPAN_END() fq_timer_span_end(ctx, st)
 
+// timing experiments only (tools/traffic_experiment.py): FQGPU_DEBUG_SKIP = bit mask of kernel groups
+// that are NOT launched; their outputs keep the values of the previous encode of the same lane
+static unsigned fq_debug_skip() {
+  const char *e = getenv("FQGPU_DEBUG_SKIP");
+  return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
+}
+
 template <class M>
 int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b,
                   const uint32_t *rec_start, uint8_t *out_dev, size_t cap) {
@@ -1332,6 +1357,10 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   const bool serial_seq = M::STREAM == 0 && !ctx->seq_generic;
 
   int rc;
+  unsigned dbg_mask = fq_debug_skip();
+  if ((dbg_mask & 256u) && M::STREAM == 1) dbg_mask = 0;  // 256: sequence stream only
+  if ((dbg_mask & 512u) && M::STREAM == 0) dbg_mask = 0;  // 512: quality stream only
+  bool dbg_off = false;
   if ((rc = sc.slot_of.reserve(((size_t)n_sym + SC_BATCH) * 4))) return rc;
   if ((rc = sc.keys.reserve(((size_t)n_sym + SC_BATCH) * 4))) return rc;
   if ((rc = sc.sorted_sym.reserve(padded))) return rc;
@@ -1366,25 +1395,33 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   const char *pfx = M::STREAM ? "qual." : "seq.";
   (void)pfx;
 
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");  dbg_off = (dbg_mask & 1u) != 0;
   static const unsigned hist_threads_q = getenv("FQGPU_HIST_THREADS") ? (unsigned)atoi(getenv("FQGPU_HIST_THREADS")) : 256u;
-  hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(M::STREAM ? hist_threads_q : 256), 0, st, b->raw, b->recs,
+  if (!dbg_off) hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(M::STREAM ? hist_threads_q : 256), 0, st, b->raw, b->recs,
                      rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), sc.keys.as<uint32_t>(), res);
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");
-  hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");  dbg_off = (dbg_mask & 2u) != 0;
+  if (!dbg_off) hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
-  hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, sc.group_sum.as<uint32_t>(), n_groups,
+  if (!dbg_off) hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, sc.group_sum.as<uint32_t>(), n_groups,
                      B, S, arrays);
-  hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
+  if (!dbg_off) hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B,
                      sc.tile_base.as<uint32_t>());
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");
-  hipLaunchKernelGGL(k_scatter<M>, dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
-                     sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>());
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");  dbg_off = (dbg_mask & 4u) != 0;
+  if (!dbg_off) {
+    if (ctx->lds_atomics_ordered)
+      hipLaunchKernelGGL((k_scatter<M, true>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+                         sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>(),
+                         getenv("FQGPU_DEBUG_NO_SYM_STORE") ? 1 : 0);
+    else
+      hipLaunchKernelGGL((k_scatter<M, false>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+                         sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>(),
+                         getenv("FQGPU_DEBUG_NO_SYM_STORE") ? 1 : 0);
+  }
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.scan" : (serial_seq ? "seq.setfunc" : "seq.scan"));
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.scan" : (serial_seq ? "seq.setfunc" : "seq.scan"));  dbg_off = (dbg_mask & 8u) != 0;
   if (serial_seq) {
     uint32_t *plan = sc.seq_plan.as<uint32_t>();
     uint16_t *entry = reinterpret_cast<uint16_t *>(plan + SEGPLAN_WORDS);
@@ -1394,9 +1431,10 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     const unsigned wpg = two ? SETS_WAVES2 : SETS_WAVES;
     const unsigned max_fitems = seq_max_segs / (wpg * SETS_ROUNDS) + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
     static const bool dbg_skip = getenv("FQGPU_DEBUG_SKIP_SEQ_CHAIN") != nullptr;  // timing experiment only: wrong output
-    hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, wpg * SETS_ROUNDS, plan);
+    if (!dbg_off) hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, wpg * SETS_ROUNDS, plan);
     if (!dbg_skip) {
-      if (two)
+      if (dbg_off) {
+      } else if (two)
         hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(min(max_fitems, ctx->n_cus)), dim3(SETS_WAVES2 * 64),
                            32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2,
                            4 * next_stride, seq_S, seq_fstride, fbuf, plan + 4 * (B + 1));
@@ -1405,11 +1443,11 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                            8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1,
                            next_stride, seq_S, seq_fstride, fbuf, plan + 4 * (B + 1));
       FQ_SPAN_END();
-      FQ_SPAN_BEGIN("seq.resolve");
-      hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, entry);
+      FQ_SPAN_BEGIN("seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
+      if (!dbg_off) hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, entry);
       FQ_SPAN_END();
-      FQ_SPAN_BEGIN("seq.chains");
-      hipLaunchKernelGGL(k_seq_emit, dim3(max_eitems), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
+      FQ_SPAN_BEGIN("seq.chains");  dbg_off = (dbg_mask & 8u) != 0;
+      if (!dbg_off) hipLaunchKernelGGL(k_seq_emit, dim3(max_eitems), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
                          sc.out16.as<uint16_t>(), arrays, plan, tab.ct, tab.ct_off, tab.next1, next_stride, seq_S,
                          entry, final_state, res);
     }
@@ -1422,45 +1460,46 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     sa.entry_state = reinterpret_cast<uint16_t *>(sa.n_opaque + 4);
     uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
     FQ_HIP(hipMemsetAsync(sa.n_opaque, 0, 4, st));
-    hipLaunchKernelGGL(k_seg_scan<M>, dim3((gen_max_segs + 3) / 4), dim3(256), 0, st, sc.sorted_sym.as<uint8_t>(),
+    if (!dbg_off) hipLaunchKernelGGL(k_seg_scan<M>, dim3((gen_max_segs + 3) / 4), dim3(256), 0, st, sc.sorted_sym.as<uint8_t>(),
                        arrays, tab.reset_mask, tab.logs, S, sa);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk1" : "seq.walk1");
-    hipLaunchKernelGGL((k_seg_walk<M, 1>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk1" : "seq.walk1");  dbg_off = (dbg_mask & 8u) != 0;
+    if (!dbg_off) hipLaunchKernelGGL((k_seg_walk<M, 1>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                        sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, sa, res);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.setfunc" : "seq.setfunc");
-    if (tab.max_log <= 11)
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.setfunc" : "seq.setfunc");  dbg_off = (dbg_mask & 8u) != 0;
+    if (dbg_off) {
+    } else if (tab.max_log <= 11)
       hipLaunchKernelGGL((k_seg_setfunc<M, 32>), dim3(n_sym / S + 1), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                          arrays, tab.ct, tab.ct_off, S, gen_fstride, sa, fbuf);
     else
       hipLaunchKernelGGL((k_seg_setfunc<M, 64>), dim3(n_sym / S + 1), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                          arrays, tab.ct, tab.ct_off, S, gen_fstride, sa, fbuf);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.resolve" : "seq.resolve");
-    hipLaunchKernelGGL(k_seg_resolve<M>, dim3((n_sym / S + 256) / 256), dim3(256), 0, st, arrays, tab.logs, fbuf,
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.resolve" : "seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
+    if (!dbg_off) hipLaunchKernelGGL(k_seg_resolve<M>, dim3((n_sym / S + 256) / 256), dim3(256), 0, st, arrays, tab.logs, fbuf,
                        gen_fstride, sa);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk2" : "seq.walk2");
-    hipLaunchKernelGGL((k_seg_walk<M, 2>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk2" : "seq.walk2");  dbg_off = (dbg_mask & 8u) != 0;
+    if (!dbg_off) hipLaunchKernelGGL((k_seg_walk<M, 2>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                        sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, sa, res);
   }
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.bitcount" : "seq.bitcount");
-  hipLaunchKernelGGL(k_bitcount, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.bitcount" : "seq.bitcount");  dbg_off = (dbg_mask & 16u) != 0;
+  if (!dbg_off) hipLaunchKernelGGL(k_bitcount, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
                      sc.out16.as<uint16_t>(), n_sym, sc.tile_bits.as<uint32_t>(), sc.keys.as<uint16_t>());
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.bitscan" : "seq.bitscan");
-  hipLaunchKernelGGL(k_bitscan, dim3(1), dim3(1024), 0, st, sc.tile_bits.as<uint32_t>(), n_ptiles,
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.bitscan" : "seq.bitscan");  dbg_off = (dbg_mask & 32u) != 0;
+  if (!dbg_off) hipLaunchKernelGGL(k_bitscan, dim3(1), dim3(1024), 0, st, sc.tile_bits.as<uint32_t>(), n_ptiles,
                      sc.tile_bit_base.as<unsigned long long>(), tab.log_prefix, B, (unsigned long long)cap,
                      reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.pack" : "seq.pack");
-  hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.keys.as<uint16_t>(), n_sym,
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.pack" : "seq.pack");  dbg_off = (dbg_mask & 64u) != 0;
+  if (!dbg_off) hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.keys.as<uint16_t>(), n_sym,
                      sc.tile_bit_base.as<unsigned long long>(), reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.epilogue" : "seq.epilogue");
-  hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, final_state, tab.logs,
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.epilogue" : "seq.epilogue");  dbg_off = (dbg_mask & 128u) != 0;
+  if (!dbg_off) hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, final_state, tab.logs,
                      tab.log_prefix, reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
   FQ_HIP(hipGetLastError());
@@ -1468,6 +1507,59 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
 }
 
 }  // namespace
+
+namespace {
+// Verifies on the device that same-address LDS atomics of one wave instruction are applied in
+// lane order (what k_scatter<ORDERED> relies on): random keys, some lanes idle, plain and packed
+// counters, compared with the rank counted by shuffles.
+__global__ void __launch_bounds__(256)
+k_probe_lds_atomic_order(unsigned iters, unsigned *__restrict__ bad) {
+  __shared__ unsigned cnt[4][1024];
+  const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
+  unsigned s = (blockIdx.x * blockDim.x + threadIdx.x) * 40503u + 12345u;
+  unsigned nbad = 0;
+  for (unsigned it = 0; it < iters; it++) {
+    for (unsigned c = lane; c < 1024; c += 64) cnt[wave][c] = 0;
+    fq_lds_wave_sync();
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    const unsigned range = 1u << ((it % 6) * 2);  // 1, 4, 16, ... 1024 distinct keys
+    const unsigned key = (s >> 8) % range;
+    const bool active = (s & 15u) != 0;
+    const bool packed = (it & 1u) != 0;
+    unsigned got = 0;
+    if (active) {
+      if (packed) got = (atomicAdd(&cnt[wave][key >> 1], 1u << (16 * (key & 1u))) >> (16 * (key & 1u))) & 0xFFFFu;
+      else got = atomicAdd(&cnt[wave][key], 1u);
+    }
+    unsigned ref = 0;
+    for (int l = 0; l < 64; l++) {
+      const unsigned k2 = (unsigned)__shfl((int)key, l);
+      const int a2 = __shfl((int)active, l);
+      if ((unsigned)l < lane && a2 && k2 == key) ref++;
+    }
+    if (active && got != ref) nbad++;
+    fq_lds_wave_sync();
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
+}  // namespace
+
+int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered) {
+  unsigned *bad = fq_dev_alloc<unsigned>(1);
+  if (!bad) return FQGPU_E_NOMEM;
+  unsigned h = 1;
+  hipError_t e = hipMemsetAsync(bad, 0, 4, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_probe_lds_atomic_order, dim3(512), dim3(256), 0, st, 96u, bad);
+    e = hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(bad);
+  if (e != hipSuccess) return FQGPU_E_HIP;
+  *ordered = h == 0;
+  return FQGPU_OK;
+}
 
 // One block = one encode lane: two HIP streams (sequence pipeline, quality pipeline) forked
 // after the record-level kernels and joined before the N-position pass.  Blocks handed to

@@ -134,6 +134,7 @@ struct fqgpu_ctx {
   unsigned seg_len = 4096;       // segment of the generic chain kernels
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
   unsigned seq_segment = 0;      // segment length of the sequence chain kernels (0 = default)
+  bool lds_atomics_ordered = false;  // probed at creation: k_scatter may rank with LDS atomics
   unsigned n_cus = 256;          // compute units of the device (grid of the persistent kernels)
   unsigned n_lanes = 4, next_lane = 0;
   EncLane lanes[FQ_MAX_LANES];
@@ -173,6 +174,7 @@ int fq_normalize_counts(hipStream_t st, const uint32_t *counts_dev, int n_models
 int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint32_t *err_dev);
 
 int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags);
+int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered);
 int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks);
 int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);
 

@@ -1,0 +1,29 @@
+"""Timing experiment (wrong output by design): how much of the step is the scattered byte stores of
+the partition kernels?  Runs the configs[1] encode step normally, then again with
+FQGPU_DEBUG_NO_SYM_STORE set (sorted_sym keeps the bytes of the previous step)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+import fqcomp28_amd as F
+import bench
+
+blocks = bench.make_workload(F, 1 << 30, 256 << 20, seed=28)
+sft, qft = bench.sample_tables(F, blocks, 128 << 20, 0)
+ctx = F.Context(sft, qft)
+dblocks = [ctx.dblock(raw, recs) for raw, recs in blocks]
+def run(steps):
+    for b in dblocks: b.encode()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for b in dblocks: b.encode()
+    ctx.sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+print("normal             %.2f ms/step" % run(4), flush=True)
+for arg in sys.argv[1:]:  # NAME or NAME=VALUE
+    name, _, val = arg.partition("=")
+    os.environ[name] = val or "1"
+    print("%-28s %.2f ms/step" % (arg, run(4)), flush=True)
+    del os.environ[name]
+print("normal again       %.2f ms/step" % run(4), flush=True)
