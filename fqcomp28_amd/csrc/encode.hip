@@ -108,10 +108,30 @@ __global__ void k_store_npos_len(const uint32_t *__restrict__ n_off, unsigned R,
 // (src/fse_sequence.cpp:76-77,101; src/fse_quality.cpp:7,19).  A wave walks a range of encode
 // indices 64 at a time; the record of every lane is found by stepping through the (few)
 // records a chunk touches with wave-uniform loads instead of a per-lane binary search.
+// The records a wave is walking through are cached 64 at a time in LDS (one coalesced load per
+// 64 records instead of a dependent global round trip in front of every 64-symbol chunk).
+struct RecCache {
+  uint32_t start[65];   // rec_start of records r0 .. r0 + 64
+  fqgpu_rec rec[64];
+};
+
 struct SymbolWalker {
   const fqgpu_rec *__restrict__ recs;
   const uint32_t *__restrict__ rec_start;
-  unsigned r;  // record holding the first symbol of the next chunk (wave-uniform)
+  unsigned r;   // record holding the first symbol of the next chunk (wave-uniform)
+  unsigned R;   // number of records
+  RecCache *cache;
+  unsigned r0;  // first cached record
+
+  __device__ __forceinline__ void refill(unsigned first) {
+    const unsigned lane = fq_lane();
+    r0 = first;
+    fq_lds_wave_sync();  // nobody still reads the old window
+    if (first + lane <= R) cache->start[lane] = rec_start[first + lane];
+    if (lane == 0 && first + 64 <= R) cache->start[64] = rec_start[first + 64];
+    if (first + lane < R) cache->rec[lane] = recs[first + lane];
+    fq_lds_wave_sync();
+  }
 
   // lanes with valid == true get their record and position; returns nothing else
   __device__ __forceinline__ void locate(unsigned eb, unsigned e_end, unsigned e, bool valid,
@@ -121,10 +141,11 @@ struct SymbolWalker {
     rec.seq_off = rec.qual_off = rec.len = 0;
     p = 0;
     for (;;) {
-      rr = __builtin_amdgcn_readfirstlane(rr);
-      const unsigned rs = rec_start[rr], rn = rec_start[rr + 1];
-      const fqgpu_rec cand = recs[rr];
-      if (valid && e >= rs && e < rn) { rec = cand; p = cand.len - 1u - (e - rs); }
+      if (rr - r0 >= 64u) refill(rr);
+      const unsigned k = rr - r0;
+      const unsigned rs = __builtin_amdgcn_readfirstlane(cache->start[k]),
+                     rn = __builtin_amdgcn_readfirstlane(cache->start[k + 1]);
+      if (valid && e >= rs && e < rn) { rec = cache->rec[k]; p = rec.len - 1u - (e - rs); }
       if (rn > chunk_end) break;            // record rr continues into the next chunk
       rr++;
       if (rn == chunk_end) break;           // next chunk starts exactly at record rr
@@ -134,14 +155,18 @@ struct SymbolWalker {
 };
 
 // ------------------------------------------------------------------ K1: per-tile context histogram
-// Also leaves key[e] = ctx | sym << 16 of every symbol in encode order, so that the
-// partition pass is a plain prefetchable linear scan.
+// Also leaves the key of every symbol in encode order, so that the partition pass is a plain
+// prefetchable linear scan: ckey[e] = ctx | sym << 8 (sequence: 10 bits) or ctx (quality: 13
+// bits, the symbol goes to csym[e]).  Two or three bytes per symbol instead of four: the key
+// stores alone were 2.7 of the 21 ms step (tools/traffic_experiment.py).
 template <class M>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
             const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
-            uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ keys, StreamResult *res) {
+            uint32_t *__restrict__ tile_hist, uint16_t *__restrict__ ckey, uint8_t *__restrict__ csym,
+            StreamResult *res, int dbg) {
   __shared__ uint32_t hist[M::B];
+  __shared__ RecCache rcache[4];  // one per wave
   const unsigned tile = blockIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
@@ -153,7 +178,8 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   const unsigned wb = min(e0 + wave * per, e1), we = min(wb + per, e1);
   bool bad = false;
   if (wb < we) {
-    SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb)};
+    SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb), R, &rcache[wave], 0};
+    w.refill(w.r);
     // two-stage pipeline: the bytes of chunk i+1 are in flight while chunk i is hashed and stored
     fqgpu_rec rec;
     unsigned p;
@@ -174,8 +200,11 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
         unsigned ctx, sym;
         fq_ctx_from_bytes<M>(cur, cur_p, ctx, sym);
         bad |= sym >= (unsigned)M::A;
-        keys[e] = ctx | ((sym & (unsigned)(M::A - 1)) << 16);
-        atomicAdd(&hist[ctx], 1u);
+        if (!(dbg & 2)) {
+          if (M::STREAM == 0) ckey[e] = (uint16_t)(ctx | ((sym & 3u) << 8));
+          else { ckey[e] = (uint16_t)ctx; csym[e] = (uint8_t)(sym & 63u); }
+        }
+        if (!(dbg & 1)) atomicAdd(&hist[ctx], 1u);
       }
       cur = nxt;
       cur_p = nxt_p;
@@ -183,6 +212,7 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   }
   if (bad) atomicOr(&res->bad_symbol, 1u);
   __syncthreads();
+  if (dbg & 1) return;  // timing experiment: the previous encode's histogram stays
   for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x)
     tile_hist[(size_t)tile * M::B + c] = hist[c];
 }
@@ -282,7 +312,7 @@ k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__
 // the batch (coalesced slot_of, scattered sorted_sym) are issued back to back afterwards.
 // (Staging the tile's partition in LDS to write whole runs was measured SLOWER: the 32 KB buffer
 // costs two thirds of the occupancy and the loop is VALU-bound on the ballot match, not on stores.)
-constexpr unsigned SC_BATCH = 2048;
+constexpr unsigned SC_BATCH = 4096;
 
 // ORDERED: the rank comes from one LDS atomic per lane instead of the ballot match.  Same-address
 // LDS atomics of ONE wave instruction take effect in lane order on gfx950 -- measured
@@ -292,88 +322,87 @@ constexpr unsigned SC_BATCH = 2048;
 // 65536 only with the last symbol of a tile that holds nothing but that context.
 template <class M, bool ORDERED>
 __global__ void __launch_bounds__(64)
-k_scatter(const uint32_t *__restrict__ keys, unsigned n_sym, unsigned T,
+k_scatter(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ csym, unsigned n_sym, unsigned T,
           const uint32_t *__restrict__ tile_base, uint8_t *__restrict__ sorted_sym,
           uint32_t *__restrict__ slot_of, int dbg_no_sym) {
   constexpr unsigned B = M::B;
-  // REL (many contexts): 16-bit cursors relative to the tile's base (a tile has at most 65536
-  // symbols), 16 KB instead of 32 KB of LDS; the base is added from the (L2-resident) tile_base
-  // row when the batch is stored
-  constexpr bool REL = B > 1024;
-  using cur_t = typename std::conditional<REL, uint16_t, uint32_t>::type;
-  __shared__ cur_t cursor[B];  // REL: rank inside the tile, else global slot
-  uint32_t *cursor32 = reinterpret_cast<uint32_t *>(cursor);
-  __shared__ uint4 kbatch4[SC_BATCH / 4], sbatch4[REL ? SC_BATCH / 8 : SC_BATCH / 4];
-  uint32_t *kbatch = reinterpret_cast<uint32_t *>(kbatch4), *sbatch = reinterpret_cast<uint32_t *>(sbatch4);
-  uint16_t *rbatch = reinterpret_cast<uint16_t *>(sbatch4);
+  constexpr bool QUAL = M::STREAM == 1;
+  // 16-bit cursors = rank inside the tile (a tile has at most 65536 symbols), two per word; the
+  // tile's base is added from the tile_base row (sequence: LDS copy; quality: L2-resident row)
+  __shared__ uint32_t cursor32[B / 2];
+  __shared__ uint32_t base[QUAL ? 1 : B];
+  __shared__ uint4 kbatch4[SC_BATCH / 8], rbatch4[SC_BATCH / 8], sbatch4[QUAL ? SC_BATCH / 16 : 1];
+  uint16_t *kbatch = reinterpret_cast<uint16_t *>(kbatch4), *rbatch = reinterpret_cast<uint16_t *>(rbatch4);
+  uint16_t *cursor = reinterpret_cast<uint16_t *>(cursor32);
+  const uint8_t *sbatch = reinterpret_cast<const uint8_t *>(sbatch4);
   const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x;
   const uint32_t *tb_row = tile_base + (size_t)tile * B;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
-  for (unsigned c = lane; c < B; c += 64) cursor[c] = REL ? (cur_t)0 : (cur_t)tb_row[c];
+  for (unsigned c = lane; c < B / 2; c += 64) cursor32[c] = 0;
+  if (!QUAL) for (unsigned c = lane; c < B; c += 64) base[c] = tb_row[c];
   fq_lds_wave_sync();
   for (unsigned b0 = e0; b0 < e1; b0 += SC_BATCH) {
     const unsigned nb = min(SC_BATCH, e1 - b0);
-    // bulk load of the batch's keys (keys + b0 is 16-byte aligned; the array is padded)
-    const uint4 *gk = reinterpret_cast<const uint4 *>(keys + b0);
+    // bulk load of the batch's keys (b0 is a multiple of 16 symbols; the arrays are padded)
+    const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + b0);
 #pragma unroll
-    for (unsigned i = 0; i < SC_BATCH / 4 / 64; i++) kbatch4[i * 64 + lane] = gk[i * 64 + lane];
+    for (unsigned i = 0; i < SC_BATCH / 8 / 64; i++) kbatch4[i * 64 + lane] = gk[i * 64 + lane];
+    if (QUAL) {
+      const uint4 *gs = reinterpret_cast<const uint4 *>(csym + b0);
+#pragma unroll
+      for (unsigned i = 0; i < SC_BATCH / 16 / 64; i++) sbatch4[i * 64 + lane] = gs[i * 64 + lane];
+    }
     fq_lds_wave_sync();
     if (ORDERED) {
       for (unsigned cb = 0; cb < nb; cb += 64) {  // no global memory operation in here
         const unsigned i = cb + lane;
         if (i < nb) {
-          const unsigned ctx = kbatch[i] & 0xFFFFu;
-          if (REL) rbatch[i] = (uint16_t)(atomicAdd(&cursor32[ctx >> 1], 1u << (16 * (ctx & 1u))) >> (16 * (ctx & 1u)));
-          else sbatch[i] = atomicAdd(&cursor32[ctx], 1u);
+          const unsigned ctx = QUAL ? (unsigned)kbatch[i] : (unsigned)kbatch[i] & 0xFFu;
+          rbatch[i] = (uint16_t)(atomicAdd(&cursor32[ctx >> 1], 1u << (16 * (ctx & 1u))) >> (16 * (ctx & 1u)));
         }
       }
       fq_lds_wave_sync();
-    } else
-    for (unsigned cb = 0; cb < nb; cb += 64) {  // no global memory operation in here
-      const unsigned i = cb + lane;
-      const bool valid = i < nb;
-      const unsigned ctx = kbatch[i] & 0xFFFFu;
-      const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
-      const unsigned rank = fq_mbcnt(grp);
-      const unsigned cur = cursor[ctx];
-      fq_lds_wave_sync();  // every lane has read its cursor before any leader advances it
-      if (valid) {
-        if (rank == 0) cursor[ctx] = (cur_t)(cur + (unsigned)__popcll(grp));
-        if (REL) rbatch[i] = (uint16_t)(cur + rank); else sbatch[i] = cur + rank;
+    } else {
+      for (unsigned cb = 0; cb < nb; cb += 64) {  // no global memory operation in here
+        const unsigned i = cb + lane;
+        const bool valid = i < nb;
+        const unsigned ctx = QUAL ? (unsigned)kbatch[i] : (unsigned)kbatch[i] & 0xFFu;
+        const unsigned long long grp = fq_match_any<M::KEYBITS>(ctx, valid);
+        const unsigned rank = fq_mbcnt(grp);
+        const unsigned cur = cursor[ctx];
+        fq_lds_wave_sync();  // every lane has read its cursor before any leader advances it
+        if (valid) {
+          if (rank == 0) cursor[ctx] = (uint16_t)(cur + (unsigned)__popcll(grp));
+          rbatch[i] = (uint16_t)(cur + rank);
+        }
+        fq_lds_wave_sync();
       }
-      fq_lds_wave_sync();
     }
-    // the batch's stores, back to back
-    if (REL) {
-      if (nb == SC_BATCH) {
-        // all gathers of the tile_base row first (one wait), then the stores: a load between
-        // two stores would wait for the older store (vmcnt retires in order)
-        unsigned slots[SC_BATCH / 64];
+    // the batch's stores, back to back: slots coalesced, symbols scattered
+    if (nb == SC_BATCH) {
+      // all gathers of the tile_base row first (one wait), then the stores: a load between
+      // two stores would wait for the older store (vmcnt retires in order)
+      unsigned slots[SC_BATCH / 64];
 #pragma unroll
-        for (unsigned j = 0; j < SC_BATCH / 64; j++) slots[j] = tb_row[kbatch[j * 64 + lane] & 0xFFFFu] + rbatch[j * 64 + lane];
+      for (unsigned j = 0; j < SC_BATCH / 64; j++) {
+        const unsigned key = kbatch[j * 64 + lane];
+        slots[j] = (QUAL ? tb_row[key] : base[key & 0xFFu]) + rbatch[j * 64 + lane];
+      }
 #pragma unroll
-        for (unsigned j = 0; j < SC_BATCH / 64; j++) {
-          slot_of[b0 + j * 64 + lane] = slots[j];
-          if (!dbg_no_sym) sorted_sym[slots[j]] = (uint8_t)(kbatch[j * 64 + lane] >> 16);
-        }
-      } else {
-        for (unsigned i = lane; i < nb; i += 64) {
-          const unsigned key = kbatch[i];
-          const unsigned slot = tb_row[key & 0xFFFFu] + rbatch[i];
-          slot_of[b0 + i] = slot;
-          sorted_sym[slot] = (uint8_t)(key >> 16);
-        }
+      for (unsigned j = 0; j < SC_BATCH / 64; j++) slot_of[b0 + j * 64 + lane] = slots[j];
+      if (!dbg_no_sym) {
+#pragma unroll
+        for (unsigned j = 0; j < SC_BATCH / 64; j++)
+          sorted_sym[slots[j]] = QUAL ? sbatch[j * 64 + lane] : (uint8_t)(kbatch[j * 64 + lane] >> 8);
       }
     } else {
-      uint4 *gs = reinterpret_cast<uint4 *>(slot_of + b0);
-      if (nb == SC_BATCH) {
-#pragma unroll
-        for (unsigned i = 0; i < SC_BATCH / 4 / 64; i++) gs[i * 64 + lane] = sbatch4[i * 64 + lane];
-      } else {
-        for (unsigned i = lane; i < nb; i += 64) slot_of[b0 + i] = sbatch[i];
+      for (unsigned i = lane; i < nb; i += 64) {
+        const unsigned key = kbatch[i];
+        const unsigned slot = (QUAL ? tb_row[key] : base[key & 0xFFu]) + rbatch[i];
+        slot_of[b0 + i] = slot;
+        sorted_sym[slot] = QUAL ? sbatch[i] : (uint8_t)(key >> 8);
       }
-      if (!dbg_no_sym) for (unsigned i = lane; i < nb; i += 64) sorted_sym[sbatch[i]] = (uint8_t)(kbatch[i] >> 16);
     }
     fq_lds_wave_sync();
   }
@@ -1332,6 +1361,12 @@ k_epilogue(const uint32_t *__restrict__ arrays, const uint16_t *__restrict__ fin
 
 // timing experiments only (tools/traffic_experiment.py): FQGPU_DEBUG_SKIP = bit mask of kernel groups
 // that are NOT launched; their outputs keep the values of the previous encode of the same lane
+// FQGPU_DEBUG_NO_SYM_STORE: 1 = both streams, 2 = sequence only, 3 = quality only
+static int fq_debug_no_sym(int stream) {
+  const char *e = getenv("FQGPU_DEBUG_NO_SYM_STORE");
+  const int v = e ? atoi(e) : 0;
+  return v == 1 || (v == 2 && stream == 0) || (v == 3 && stream == 1);
+}
 static unsigned fq_debug_skip() {
   const char *e = getenv("FQGPU_DEBUG_SKIP");
   return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
@@ -1361,8 +1396,11 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if ((dbg_mask & 256u) && M::STREAM == 1) dbg_mask = 0;  // 256: sequence stream only
   if ((dbg_mask & 512u) && M::STREAM == 0) dbg_mask = 0;  // 512: quality stream only
   bool dbg_off = false;
-  if ((rc = sc.slot_of.reserve(((size_t)n_sym + SC_BATCH) * 4))) return rc;
-  if ((rc = sc.keys.reserve(((size_t)n_sym + SC_BATCH) * 4))) return rc;
+  // keys: ckey u16 | csym u8 (quality), later enc16 u16 over both;  slot_of: u32 -- padded by one batch
+  const size_t n_pad = ((size_t)n_sym + SC_BATCH + 15) & ~(size_t)15;  // keeps every sub-array 16-byte aligned
+  static_assert(TILE_SEQ % PACK_TILE == 0 && TILE_QUAL % PACK_TILE == 0, "a packing tile lies inside one partition tile");
+  if ((rc = sc.slot_of.reserve(n_pad * 4))) return rc;
+  if ((rc = sc.keys.reserve(n_pad * 3))) return rc;
   if ((rc = sc.sorted_sym.reserve(padded))) return rc;
   if ((rc = sc.out16.reserve(padded * 2))) return rc;
   if ((rc = sc.tile_hist.reserve((size_t)n_tiles * B * 4))) return rc;
@@ -1389,6 +1427,9 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
   if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
 
+  uint16_t *ckey = sc.keys.as<uint16_t>();
+  uint8_t *csym = reinterpret_cast<uint8_t *>(ckey + n_pad);
+  uint16_t *enc16 = ckey;  // the keys are dead after K3
   uint32_t *arrays = sc.ctx_arrays.as<uint32_t>();
   uint16_t *final_state = sc.seg_state.as<uint16_t>();
   const unsigned lds_ct = (1u + (1u << (tab.max_log - 1)) + 2u * M::A) * 4u;
@@ -1396,9 +1437,9 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   (void)pfx;
 
   FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");  dbg_off = (dbg_mask & 1u) != 0;
-  static const unsigned hist_threads_q = getenv("FQGPU_HIST_THREADS") ? (unsigned)atoi(getenv("FQGPU_HIST_THREADS")) : 256u;
-  if (!dbg_off) hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(M::STREAM ? hist_threads_q : 256), 0, st, b->raw, b->recs,
-                     rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), sc.keys.as<uint32_t>(), res);
+  if (!dbg_off) hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs,
+                     rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), ckey, csym, res,
+                     getenv("FQGPU_DEBUG_K1") ? atoi(getenv("FQGPU_DEBUG_K1")) : 0);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");  dbg_off = (dbg_mask & 2u) != 0;
   if (!dbg_off) hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
@@ -1412,13 +1453,13 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");  dbg_off = (dbg_mask & 4u) != 0;
   if (!dbg_off) {
     if (ctx->lds_atomics_ordered)
-      hipLaunchKernelGGL((k_scatter<M, true>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+      hipLaunchKernelGGL((k_scatter<M, true>), dim3(n_tiles), dim3(64), 0, st, ckey, csym, n_sym, T,
                          sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>(),
-                         getenv("FQGPU_DEBUG_NO_SYM_STORE") ? 1 : 0);
+                         fq_debug_no_sym(M::STREAM));
     else
-      hipLaunchKernelGGL((k_scatter<M, false>), dim3(n_tiles), dim3(64), 0, st, sc.keys.as<uint32_t>(), n_sym, T,
+      hipLaunchKernelGGL((k_scatter<M, false>), dim3(n_tiles), dim3(64), 0, st, ckey, csym, n_sym, T,
                          sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>(),
-                         getenv("FQGPU_DEBUG_NO_SYM_STORE") ? 1 : 0);
+                         fq_debug_no_sym(M::STREAM));
   }
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.scan" : (serial_seq ? "seq.setfunc" : "seq.scan"));  dbg_off = (dbg_mask & 8u) != 0;
@@ -1487,7 +1528,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.bitcount" : "seq.bitcount");  dbg_off = (dbg_mask & 16u) != 0;
   if (!dbg_off) hipLaunchKernelGGL(k_bitcount, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
-                     sc.out16.as<uint16_t>(), n_sym, sc.tile_bits.as<uint32_t>(), sc.keys.as<uint16_t>());
+                     sc.out16.as<uint16_t>(), n_sym, sc.tile_bits.as<uint32_t>(), enc16);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.bitscan" : "seq.bitscan");  dbg_off = (dbg_mask & 32u) != 0;
   if (!dbg_off) hipLaunchKernelGGL(k_bitscan, dim3(1), dim3(1024), 0, st, sc.tile_bits.as<uint32_t>(), n_ptiles,
@@ -1495,7 +1536,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.pack" : "seq.pack");  dbg_off = (dbg_mask & 64u) != 0;
-  if (!dbg_off) hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.keys.as<uint16_t>(), n_sym,
+  if (!dbg_off) hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, enc16, n_sym,
                      sc.tile_bit_base.as<unsigned long long>(), reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.epilogue" : "seq.epilogue");  dbg_off = (dbg_mask & 128u) != 0;
