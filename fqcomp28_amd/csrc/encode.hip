@@ -312,7 +312,9 @@ k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__
 // the batch (coalesced slot_of, scattered sorted_sym) are issued back to back afterwards.
 // (Staging the tile's partition in LDS to write whole runs was measured SLOWER: the 32 KB buffer
 // costs two thirds of the occupancy and the loop is VALU-bound on the ballot match, not on stores.)
-constexpr unsigned SC_BATCH = 4096;
+constexpr unsigned SC_BATCH = 4096;      // quality: 36 KB of LDS per wave
+constexpr unsigned SC_BATCH_SEQ = 8192;  // sequence: 32 bytes per context and batch
+
 
 // ORDERED: the rank comes from one LDS atomic per lane instead of the ballot match.  Same-address
 // LDS atomics of ONE wave instruction take effect in lane order on gfx950 -- measured
@@ -327,11 +329,12 @@ k_scatter(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ csym, u
           uint32_t *__restrict__ slot_of, int dbg_no_sym) {
   constexpr unsigned B = M::B;
   constexpr bool QUAL = M::STREAM == 1;
+  constexpr unsigned BATCH = QUAL ? SC_BATCH : SC_BATCH_SEQ;
   // 16-bit cursors = rank inside the tile (a tile has at most 65536 symbols), two per word; the
   // tile's base is added from the tile_base row (sequence: LDS copy; quality: L2-resident row)
   __shared__ uint32_t cursor32[B / 2];
   __shared__ uint32_t base[QUAL ? 1 : B];
-  __shared__ uint4 kbatch4[SC_BATCH / 8], rbatch4[SC_BATCH / 8], sbatch4[QUAL ? SC_BATCH / 16 : 1];
+  __shared__ uint4 kbatch4[BATCH / 8], rbatch4[BATCH / 8], sbatch4[QUAL ? BATCH / 16 : 1];
   uint16_t *kbatch = reinterpret_cast<uint16_t *>(kbatch4), *rbatch = reinterpret_cast<uint16_t *>(rbatch4);
   uint16_t *cursor = reinterpret_cast<uint16_t *>(cursor32);
   const uint8_t *sbatch = reinterpret_cast<const uint8_t *>(sbatch4);
@@ -342,16 +345,16 @@ k_scatter(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ csym, u
   for (unsigned c = lane; c < B / 2; c += 64) cursor32[c] = 0;
   if (!QUAL) for (unsigned c = lane; c < B; c += 64) base[c] = tb_row[c];
   fq_lds_wave_sync();
-  for (unsigned b0 = e0; b0 < e1; b0 += SC_BATCH) {
-    const unsigned nb = min(SC_BATCH, e1 - b0);
+  for (unsigned b0 = e0; b0 < e1; b0 += BATCH) {
+    const unsigned nb = min(BATCH, e1 - b0);
     // bulk load of the batch's keys (b0 is a multiple of 16 symbols; the arrays are padded)
     const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + b0);
 #pragma unroll
-    for (unsigned i = 0; i < SC_BATCH / 8 / 64; i++) kbatch4[i * 64 + lane] = gk[i * 64 + lane];
+    for (unsigned i = 0; i < BATCH / 8 / 64; i++) kbatch4[i * 64 + lane] = gk[i * 64 + lane];
     if (QUAL) {
       const uint4 *gs = reinterpret_cast<const uint4 *>(csym + b0);
 #pragma unroll
-      for (unsigned i = 0; i < SC_BATCH / 16 / 64; i++) sbatch4[i * 64 + lane] = gs[i * 64 + lane];
+      for (unsigned i = 0; i < BATCH / 16 / 64; i++) sbatch4[i * 64 + lane] = gs[i * 64 + lane];
     }
     fq_lds_wave_sync();
     if (ORDERED) {
@@ -380,20 +383,20 @@ k_scatter(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ csym, u
       }
     }
     // the batch's stores, back to back: slots coalesced, symbols scattered
-    if (nb == SC_BATCH) {
+    if (nb == BATCH) {
       // all gathers of the tile_base row first (one wait), then the stores: a load between
       // two stores would wait for the older store (vmcnt retires in order)
-      unsigned slots[SC_BATCH / 64];
+      unsigned slots[BATCH / 64];
 #pragma unroll
-      for (unsigned j = 0; j < SC_BATCH / 64; j++) {
+      for (unsigned j = 0; j < BATCH / 64; j++) {
         const unsigned key = kbatch[j * 64 + lane];
         slots[j] = (QUAL ? tb_row[key] : base[key & 0xFFu]) + rbatch[j * 64 + lane];
       }
 #pragma unroll
-      for (unsigned j = 0; j < SC_BATCH / 64; j++) slot_of[b0 + j * 64 + lane] = slots[j];
+      for (unsigned j = 0; j < BATCH / 64; j++) slot_of[b0 + j * 64 + lane] = slots[j];
       if (!dbg_no_sym) {
 #pragma unroll
-        for (unsigned j = 0; j < SC_BATCH / 64; j++)
+        for (unsigned j = 0; j < BATCH / 64; j++)
           sorted_sym[slots[j]] = QUAL ? sbatch[j * 64 + lane] : (uint8_t)(kbatch[j * 64 + lane] >> 8);
       }
     } else {
@@ -1145,25 +1148,105 @@ k_seg_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
 
 // Entry states behind opaque segments.  Every other entry state is already there: k_seg_scan
 // stored the initial state of every chain, k_seg_walk<1> the state behind every transparent
-// segment.  One thread per RUN of consecutive opaque segments: x <- F[x], segment after segment.
+// segment.  A run of opaque segments is a chain x <- F_k[x] of dependent loads (0.5 us each;
+// 29 K of them in a row for a block of constant qualities), so it is resolved in three levels
+// over the walk kernels' items (64 consecutive segments of a chain):
+//  k_seg_compose   one wave per item with an opaque segment: G = composition of the item's
+//                  segment functions (a transparent segment contributes a constant), for every
+//                  possible entry state of the item
+//  k_seg_resolve2  one thread per context: entry state of every item, x <- G_item[x]
+//  k_seg_resolve3  one lane per such item: entry state of every segment inside the item
+struct ItemArrays {
+  uint16_t *g;           // [items][fstride] composed function (items flagged in has_g only)
+  uint32_t *has_g;       // [items]
+  uint16_t *item_entry;  // [items]
+};
+
+template <class M, unsigned PER0>
+__global__ void __launch_bounds__(64)
+k_seg_compose(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ logs,
+              const uint16_t *__restrict__ fbuf, unsigned fstride, SegArrays sa, ItemArrays ia) {
+  constexpr unsigned B = M::B;
+  const uint32_t *seg_base = arrays + B + (B + 1), *item_base = seg_base + B + 1;
+  const unsigned item = blockIdx.x, lane = fq_lane();
+  if (item >= item_base[B]) return;  // the grid is an upper bound
+  const unsigned c = seg_ctx_of<M>(item_base, item);
+  const unsigned nseg = seg_base[c + 1] - seg_base[c];
+  const unsigned k0 = (item - item_base[c]) * 64, n_here = min(64u, nseg - k0);
+  const unsigned seg0 = seg_base[c] + k0;
+  // lane t looks at segment t of the item: function slot (SEG_NONE: transparent or last of the chain)
+  const unsigned slot = lane < n_here ? sa.fidx[seg0 + lane] : SEG_NONE;
+  const unsigned long long opaque = __ballot(slot != SEG_NONE);
+  if (lane == 0) ia.has_g[item] = opaque != 0ull;
+  if (!opaque) return;
+  const unsigned exit_state = lane < n_here && slot == SEG_NONE && k0 + lane + 1 < nseg ? sa.entry_state[seg0 + lane + 1] : 0u;
+  const unsigned size = 1u << logs[c], per = max(size >> 6, 1u);
+  unsigned x[PER0];
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) x[j] = size + ((lane + 64u * j) & (size - 1));
+  for (unsigned t = 0; t < n_here; t++) {
+    const unsigned sl = (unsigned)__shfl((int)slot, (int)t);
+    if (sl == SEG_NONE) {
+      if (k0 + t + 1 >= nseg) break;  // last segment of the chain: nothing follows
+      const unsigned e = (unsigned)__shfl((int)exit_state, (int)t);
+#pragma unroll
+      for (unsigned j = 0; j < PER0; j++) x[j] = e;
+    } else {
+      const uint16_t *f = fbuf + (size_t)sl * fstride;
+#pragma unroll
+      for (unsigned j = 0; j < PER0; j++)
+        if (j < per) x[j] = f[x[j] - size];
+    }
+  }
+  uint16_t *g = ia.g + (size_t)item * fstride;
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) {
+    const unsigned xi = lane + 64u * j;
+    if (j < per && xi < size) g[xi] = (uint16_t)x[j];
+  }
+}
+
 template <class M>
 __global__ void __launch_bounds__(256)
-k_seg_resolve(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ logs,
-              const uint16_t *__restrict__ fbuf, unsigned fstride, SegArrays sa) {
+k_seg_resolve2(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ logs, unsigned fstride,
+               SegArrays sa, ItemArrays ia) {
   constexpr unsigned B = M::B;
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= *sa.n_opaque) return;  // the grid is an upper bound
-  const unsigned e = sa.olist[i];
-  unsigned seg = e & 0x7FFFFFFFu;
-  // a run starts at the first segment of a chain or behind a transparent segment
-  if (!(e >> 31) && sa.first_reset[seg - 1] == SEG_NONE) return;
-  const uint32_t *seg_base = arrays + B + (B + 1);
-  const unsigned size = 1u << logs[seg_ctx_of<M>(seg_base, seg)];
-  unsigned x = sa.entry_state[seg];
-  for (unsigned slot = i; slot != SEG_NONE; slot = sa.fidx[seg]) {
-    x = fbuf[(size_t)slot * fstride + (x - size)];
-    sa.entry_state[++seg] = (uint16_t)x;
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B) return;
+  const uint32_t *seg_base = arrays + B + (B + 1), *item_base = seg_base + B + 1;
+  const unsigned i0 = item_base[c], ni = item_base[c + 1] - i0;
+  const unsigned size = 1u << logs[c];
+  unsigned x = size;  // FSE_initCState
+  for (unsigned i = 0; i < ni; i++) {
+    ia.item_entry[i0 + i] = (uint16_t)x;
+    if (i + 1 == ni) break;
+    // an item without opaque segments ends behind a transparent one: k_seg_walk<1> left that state
+    x = ia.has_g[i0 + i] ? ia.g[(size_t)(i0 + i) * fstride + (x - size)]
+                         : sa.entry_state[seg_base[c] + (i + 1) * 64];
   }
+}
+
+template <class M>
+__global__ void __launch_bounds__(256)
+k_seg_resolve3(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ logs,
+               const uint16_t *__restrict__ fbuf, unsigned fstride, SegArrays sa, ItemArrays ia) {
+  constexpr unsigned B = M::B;
+  const uint32_t *seg_base = arrays + B + (B + 1), *item_base = seg_base + B + 1;
+  const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= item_base[B] || !ia.has_g[item]) return;
+  const unsigned c = seg_ctx_of<M>(item_base, item);
+  const unsigned nseg = seg_base[c + 1] - seg_base[c];
+  const unsigned k0 = (item - item_base[c]) * 64, n_here = min(64u, nseg - k0);
+  const unsigned seg0 = seg_base[c] + k0;
+  const unsigned size = 1u << logs[c];
+  unsigned x = ia.item_entry[item];
+  for (unsigned t = 0; t < n_here; t++) {
+    sa.entry_state[seg0 + t] = (uint16_t)x;
+    if (k0 + t + 1 >= nseg) break;
+    const unsigned sl = sa.fidx[seg0 + t];
+    x = sl == SEG_NONE ? (unsigned)sa.entry_state[seg0 + t + 1] : (unsigned)fbuf[(size_t)sl * fstride + (x - size)];
+  }
+  if (k0 + n_here < nseg) sa.entry_state[seg0 + n_here] = (uint16_t)x;  // first segment of the next item
 }
 
 // ------------------------------------------------------------------ K6: bit offsets and packing
@@ -1397,7 +1480,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if ((dbg_mask & 512u) && M::STREAM == 0) dbg_mask = 0;  // 512: quality stream only
   bool dbg_off = false;
   // keys: ckey u16 | csym u8 (quality), later enc16 u16 over both;  slot_of: u32 -- padded by one batch
-  const size_t n_pad = ((size_t)n_sym + SC_BATCH + 15) & ~(size_t)15;  // keeps every sub-array 16-byte aligned
+  const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15;  // keeps every sub-array 16-byte aligned
   static_assert(TILE_SEQ % PACK_TILE == 0 && TILE_QUAL % PACK_TILE == 0, "a packing tile lies inside one partition tile");
   if ((rc = sc.slot_of.reserve(n_pad * 4))) return rc;
   if ((rc = sc.keys.reserve(n_pad * 3))) return rc;
@@ -1417,7 +1500,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   const unsigned gen_max_segs = n_sym / S + B + 1;
   const unsigned gen_fstride = 1u << tab.max_log;
   if (!serial_seq) {
-    if ((rc = sc.seg_arrays.reserve((size_t)gen_max_segs * 16 + 64))) return rc;
+    if ((rc = sc.seg_arrays.reserve((size_t)gen_max_segs * 16 + 64 + (size_t)max_items * (2 * gen_fstride + 8) + 64))) return rc;
     if ((rc = sc.seq_fbuf.reserve(((size_t)n_sym / S + 2) * gen_fstride * 2 + 64))) return rc;
   }
   if (serial_seq) {
@@ -1518,8 +1601,19 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                          arrays, tab.ct, tab.ct_off, S, gen_fstride, sa, fbuf);
     FQ_SPAN_END();
     FQ_SPAN_BEGIN(M::STREAM ? "qual.resolve" : "seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
-    if (!dbg_off) hipLaunchKernelGGL(k_seg_resolve<M>, dim3((n_sym / S + 256) / 256), dim3(256), 0, st, arrays, tab.logs, fbuf,
-                       gen_fstride, sa);
+    if (!dbg_off) {
+      ItemArrays ia;
+      ia.has_g = reinterpret_cast<uint32_t *>(sc.seg_arrays.as<uint8_t>() + (((size_t)gen_max_segs * 16 + 64 + 15) & ~(size_t)15));
+      ia.item_entry = reinterpret_cast<uint16_t *>(ia.has_g + max_items);
+      ia.g = ia.item_entry + ((max_items + 7) & ~7u);
+      if (tab.max_log <= 11)
+        hipLaunchKernelGGL((k_seg_compose<M, 32>), dim3(max_items), dim3(64), 0, st, arrays, tab.logs, fbuf, gen_fstride, sa, ia);
+      else
+        hipLaunchKernelGGL((k_seg_compose<M, 64>), dim3(max_items), dim3(64), 0, st, arrays, tab.logs, fbuf, gen_fstride, sa, ia);
+      hipLaunchKernelGGL(k_seg_resolve2<M>, dim3((B + 255) / 256), dim3(256), 0, st, arrays, tab.logs, gen_fstride, sa, ia);
+      hipLaunchKernelGGL(k_seg_resolve3<M>, dim3((max_items + 255) / 256), dim3(256), 0, st, arrays, tab.logs, fbuf,
+                         gen_fstride, sa, ia);
+    }
     FQ_SPAN_END();
     FQ_SPAN_BEGIN(M::STREAM ? "qual.walk2" : "seq.walk2");  dbg_off = (dbg_mask & 8u) != 0;
     if (!dbg_off) hipLaunchKernelGGL((k_seg_walk<M, 2>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
