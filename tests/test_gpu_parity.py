@@ -238,6 +238,40 @@ def test_sequence_segment_functions_are_exact(F, bases, segment):
     ctx.close()
 
 
+@pytest.mark.parametrize("segment", [1024, 4096])
+@pytest.mark.parametrize("quals", ["binned", "two_levels_rare_third"])
+def test_quality_tables_without_reset_symbols(F, quals, segment):
+    """Binned qualities: no symbol has a normalised count of 1, so (almost) every quality segment is
+    opaque and gets its entry state from segment functions composed over runs of many segments
+    (k_seg_setfunc / k_seg_compose / k_seg_resolve2/3); a rare third level adds a few transparent
+    segments in between."""
+    raw, recs = _synth(F, 2, 6 << 20)
+    rng = np.random.default_rng(11)
+    n = int(recs["len"].sum())
+    keep = rng.random(n) < 0.85
+    keep[0] = False
+    if quals == "binned":
+        levels, p = np.frombuffer(b"#-8F", dtype=np.uint8), [0.05, 0.1, 0.15, 0.7]
+    else:
+        levels, p = np.frombuffer(b"#F:", dtype=np.uint8), [0.3, 0.69995, 0.00005]
+    fresh = rng.choice(len(levels), size=n, p=p)
+    q = levels[fresh[np.maximum.accumulate(np.where(keep, 0, np.arange(n)))]]
+    raw = raw.copy()
+    at = 0
+    for r in recs:
+        raw[r["qual_off"]: r["qual_off"] + r["len"]] = q[at: at + r["len"]]
+        at += int(r["len"])
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    ctx.set_chain_params(segment)
+    g = ctx.encode_block(raw, recs)
+    assert_same_encoding(g, e)
+    rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
 @pytest.mark.parametrize("mode,size", [(2, 12 << 20), (4, 12 << 20)])
 def test_config2_and_config4_blocks_match_oracle(F, mode, size):
     """configs[1]/[3] at 12 MiB: tables from a different sample (first 4 MiB) than the coded block."""
