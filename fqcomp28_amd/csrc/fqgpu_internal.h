@@ -113,8 +113,7 @@ struct EncScratch {
 };
 
 // One encode lane: everything a block needs while it is being coded, so that several
-// blocks can be in flight on one GPU (two HIP streams: sequence pipeline at high priority,
-// quality pipeline at low priority).
+// blocks can be in flight on one GPU (two HIP streams: sequence pipeline, quality pipeline).
 struct EncLane {
   hipStream_t st_seq = nullptr, st_qual = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
