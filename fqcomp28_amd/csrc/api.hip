@@ -169,7 +169,7 @@ static void free_lane(EncLane &l) {
   for (int s = 0; s < 2; s++) {
     EncScratch &e = l.enc[s];
     DevBuf *eb[] = {&e.slot_of, &e.keys, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
-                    &e.ctx_arrays, &e.seg_state, &e.seg_arrays, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
+                    &e.ctx_arrays, &e.seg_state, &e.seg_arrays, &e.seq_bdesc, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
     for (DevBuf *b : eb) b->release();
   }
   hipEvent_t evs[] = {l.ev_fork, l.ev_join};

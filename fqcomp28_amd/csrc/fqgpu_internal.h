@@ -105,6 +105,7 @@ struct EncScratch {
   DevBuf ctx_arrays;  // ctx_count[B], ctx_start[B+1], seg_base[B+1], item_base[B+1]
   DevBuf seg_state;   // u16 final_state[B]
   DevBuf seg_arrays;  // generic chain kernels: per-segment tables (encode.hip: SegArrays)
+  DevBuf seq_bdesc;   // sequence stream: batch descriptors of the batch-sorted partition (encode.hip: SeqBatchDesc)
   DevBuf seq_plan;    // segment plan of the sequence chains (encode.hip: SEGPLAN_WORDS) + entry states
   DevBuf seq_fbuf;    // u16 [segments][1 << max_log] segment functions F: entry state -> exit state
   DevBuf tile_bits;   // u32 [ptiles]
