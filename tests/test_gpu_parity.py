@@ -157,6 +157,28 @@ def test_chain_parameters_never_change_the_bits(F, golden_dir, seg, seq_generic,
     ctx.close()
 
 
+def test_partition_fallback_without_lane_ordered_lds_atomics(F, golden_dir, monkeypatch):
+    """The partition kernels rank with lane-ordered LDS atomics when the handle's probe confirms the
+    ordering; FQGPU_NO_LDS_ATOMIC_RANK forces the ballot-match kernels a device without that
+    property would get.  Same bits either way."""
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_2.fastq"))
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    monkeypatch.setenv("FQGPU_NO_LDS_ATOMIC_RANK", "1")
+    ctx = F.Context(sft, qft)
+    monkeypatch.delenv("FQGPU_NO_LDS_ATOMIC_RANK")
+    g = ctx.encode_block(raw, recs)
+    assert_same_encoding(g, e)
+    big, brecs = _synth(F, 2, 6 << 20)
+    _, _, sft2, qft2 = O.freq_tables(big, brecs)
+    ctx.close()
+    monkeypatch.setenv("FQGPU_NO_LDS_ATOMIC_RANK", "1")
+    ctx = F.Context(sft2, qft2)
+    monkeypatch.delenv("FQGPU_NO_LDS_ATOMIC_RANK")
+    assert_same_encoding(ctx.encode_block(big, brecs), O.OracleCtx(sft2, qft2).encode(big, brecs))
+    ctx.close()
+
+
 def _qual_ctx_of(raw, recs):
     """context of every quality symbol (numpy restatement of FSE_Quality::calcContext)."""
     out = []
