@@ -115,6 +115,8 @@ struct RecCache {
   fqgpu_rec rec[64];
 };
 
+constexpr int K1_DEPTH = 4;  // chunk buffers of K1's software pipeline
+
 struct SymbolWalker {
   const fqgpu_rec *__restrict__ recs;
   const uint32_t *__restrict__ rec_start;
@@ -123,17 +125,20 @@ struct SymbolWalker {
   RecCache *cache;
   unsigned r0;  // first cached record
 
-  __device__ __forceinline__ void refill(unsigned first) {
+  // window of 64 records starting at `first`; returns the first encode index it does NOT cover
+  __device__ __forceinline__ unsigned refill(unsigned first) {
     const unsigned lane = fq_lane();
     r0 = first;
     fq_lds_wave_sync();  // nobody still reads the old window
-    if (first + lane <= R) cache->start[lane] = rec_start[first + lane];
-    if (lane == 0 && first + 64 <= R) cache->start[64] = rec_start[first + 64];
+    cache->start[lane] = first + lane <= R ? rec_start[first + lane] : 0xFFFFFFFFu;
+    if (lane == 0) cache->start[64] = first + 64 <= R ? rec_start[first + 64] : 0xFFFFFFFFu;
     if (first + lane < R) cache->rec[lane] = recs[first + lane];
     fq_lds_wave_sync();
+    return __builtin_amdgcn_readfirstlane(cache->start[64]);
   }
 
-  // lanes with valid == true get their record and position; returns nothing else
+  // lanes with valid == true get their record and position.  The chunk [eb, eb + 64) must lie
+  // inside the cached window (no global memory operation in here).
   __device__ __forceinline__ void locate(unsigned eb, unsigned e_end, unsigned e, bool valid,
                                          fqgpu_rec &rec, unsigned &p) {
     const unsigned chunk_end = min(eb + 64u, e_end);
@@ -141,7 +146,6 @@ struct SymbolWalker {
     rec.seq_off = rec.qual_off = rec.len = 0;
     p = 0;
     for (;;) {
-      if (rr - r0 >= 64u) refill(rr);
       const unsigned k = rr - r0;
       const unsigned rs = __builtin_amdgcn_readfirstlane(cache->start[k]),
                      rn = __builtin_amdgcn_readfirstlane(cache->start[k + 1]);
@@ -179,26 +183,30 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   bool bad = false;
   if (wb < we) {
     SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb), R, &rcache[wave], 0};
-    w.refill(w.r);
-    // two-stage pipeline: the bytes of chunk i+1 are in flight while chunk i is hashed and stored
-    fqgpu_rec rec;
-    unsigned p;
-    w.locate(wb, we, wb + lane, wb + lane < we, rec, p);
-    SymBytes cur = fq_load_sym_bytes<M>(raw, rec, p, wb + lane < we);
-    unsigned cur_p = p;
-    for (unsigned eb = wb; eb < we; eb += 64) {
-      const unsigned e = eb + lane;
-      const bool valid = e < we;
-      SymBytes nxt = cur;
-      unsigned nxt_p = 0;
-      if (eb + 64 < we) {
-        const bool nvalid = e + 64 < we;
-        w.locate(eb + 64, we, e + 64, nvalid, rec, nxt_p);
-        nxt = fq_load_sym_bytes<M>(raw, rec, nxt_p, nvalid);
-      }
-      if (valid) {
+    // Software pipeline over a ring of K1_DEPTH chunk buffers: the bytes of chunk i + K1_DEPTH - 1
+    // are requested before chunk i is hashed, so a load has K1_DEPTH - 1 chunks of work to land.
+    // (A two-stage version with "cur = nxt" at the end of the iteration made the register copy
+    // wait for the load it had just issued: the full global latency in every iteration.)  The
+    // pipeline runs over the chunks that lie inside one 64-record window of the LDS cache, so that
+    // its body contains no global memory operation besides the byte loads and the key stores and
+    // the compiler can keep several chunks' loads outstanding.
+    SymBytes buf[K1_DEPTH];
+    unsigned bp[K1_DEPTH];
+    unsigned lim = 0;  // end (encode index) of the chunks of the current window
+    auto fetch = [&](int slot, unsigned eb2) {
+      const unsigned e2 = eb2 + lane;
+      const bool v2 = e2 < lim;
+      fqgpu_rec rec;
+      unsigned p;
+      w.locate(eb2, lim, e2, v2, rec, p);
+      buf[slot] = fq_load_sym_bytes<M>(raw, rec, p, v2);
+      bp[slot] = p;
+    };
+    auto consume = [&](int slot, unsigned eb2) {
+      const unsigned e = eb2 + lane;
+      if (e < lim) {
         unsigned ctx, sym;
-        fq_ctx_from_bytes<M>(cur, cur_p, ctx, sym);
+        fq_ctx_from_bytes<M>(buf[slot], bp[slot], ctx, sym);
         bad |= sym >= (unsigned)M::A;
         if (!(dbg & 2)) {
           if (M::STREAM == 0) ckey[e] = (uint16_t)(ctx | ((sym & 3u) << 8));
@@ -206,8 +214,34 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
         }
         if (!(dbg & 1)) atomicAdd(&hist[ctx], 1u);
       }
-      cur = nxt;
-      cur_p = nxt_p;
+    };
+    for (unsigned eb = wb; eb < we;) {
+      const unsigned covered = w.refill(w.r);  // records w.r .. w.r + 63
+      // whole chunks inside the window (the wave's last chunk may be short)
+      lim = covered >= we ? we : wb + ((covered - wb) & ~63u);
+#pragma unroll
+      for (int d = 0; d < K1_DEPTH - 1; d++)
+        if (eb + 64u * d < lim) fetch(d, eb + 64u * d);
+      // steady state: straight-line fetch / consume (no branch the load counters could get lost in)
+      for (; eb + 64u * (2 * K1_DEPTH - 2) < lim; eb += 64u * K1_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < K1_DEPTH; d++) {
+          fetch((d + K1_DEPTH - 1) % K1_DEPTH, eb + 64u * (d + K1_DEPTH - 1));
+          consume(d, eb + 64u * d);
+        }
+      }
+      for (; eb < lim; eb += 64u * K1_DEPTH) {  // drain
+#pragma unroll
+        for (int d = 0; d < K1_DEPTH; d++) {
+          const unsigned cur = eb + 64u * d;
+          if (cur < lim) {
+            const unsigned nxt = cur + 64u * (K1_DEPTH - 1);
+            if (nxt < lim) fetch((d + K1_DEPTH - 1) % K1_DEPTH, nxt);
+            consume(d, cur);
+          }
+        }
+      }
+      eb = lim;
     }
   }
   if (bad) atomicOr(&res->bad_symbol, 1u);

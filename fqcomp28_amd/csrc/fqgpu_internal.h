@@ -274,11 +274,15 @@ struct SymBytes {
 template <class M>
 __device__ __forceinline__ SymBytes fq_load_sym_bytes(const uint8_t *__restrict__ raw, const fqgpu_rec &rec,
                                                       unsigned p, bool valid) {
+  // Unconditional loads from clamped positions (an idle lane has rec = {0, 0, 0}, p = 0 and reads
+  // byte 0 of the block): straight-line code lets the compiler keep several chunks' loads in
+  // flight; bytes in front of the read are ignored by fq_ctx_from_bytes (its p >= k tests).
+  (void)valid;
   SymBytes r;
   const uint8_t *s = raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off);
   constexpr int N = M::STREAM == 0 ? 5 : 4;
 #pragma unroll
-  for (int k = 0; k < 5; k++) r.b[k] = (k < N && valid && p >= (unsigned)k) ? (unsigned)s[p - k] : 0u;
+  for (int k = 0; k < 5; k++) r.b[k] = k < N ? (unsigned)s[p >= (unsigned)k ? p - k : 0u] : 0u;
   return r;
 }
 
