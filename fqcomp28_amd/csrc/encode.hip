@@ -11,19 +11,22 @@
 // ctx(e)/sym(e) depend on the INPUT only, each context's state chain only on the
 // symbols of that context.  Hence the decomposition:
 //   K1 tile_hist / K2 layout : counting sort keys = context, per-tile histograms + scan
-//   K3 scatter               : stable partition of the symbols by context
-//   K4 chains                : a tANS encoder state does NOT forget its history (measured:
-//                              with near power-of-two counts the transition is a near-
-//                              permutation of the reachable states), so a chain can only be
-//                              cut where the state is known without its past: right after a
-//                              symbol whose normalised count is 1 or -1 (ONE table cell, the
-//                              next state is the same from every state).  Quality chains are
-//                              cut at those "reset" symbols, one lane per piece, CTable in
-//                              LDS.  Sequence contexts have no such symbols (4 symbols of
-//                              ~1/4 each): one lane walks each (block, context) chain with a
-//                              [symbol][state] -> state table in LDS, and the parallelism is
-//                              contexts x blocks in flight.
-//   K6 bitcount/scan/pack    : per-symbol (nb,bits) gathered back into encode order,
+//   K3 scatter               : stable partition of the symbols by context (rank inside a
+//                              (tile, context) = one lane-ordered LDS atomic per symbol); the
+//                              sequence stream sorts every 4 K batch by context in LDS and
+//                              writes runs instead of scattered bytes
+//   K4 chains                : a tANS encoder state never forgets its history completely, but
+//                              the SET of states it can be in collapses fast.  A chain is cut
+//                              into segments of 4096 symbols; the state is known without its
+//                              past right after a symbol whose normalised count is 1 or -1 (one
+//                              table cell: "reset"), and for a segment without such a symbol
+//                              one wave computes the segment's FUNCTION entry state -> exit
+//                              state for every possible entry state over collapsing state sets.
+//                              Entry states follow by applying the functions along the chain;
+//                              then one lane per segment emits (nb, bits).  No serial chain,
+//                              no speculation.
+//   K6 bitcount/scan/pack    : per-symbol (nb,bits) brought back into encode order (quality:
+//                              gather by slot; sequence: runs of the batch read into LDS),
 //                              exclusive scan of nb = bit offsets, bit packing through LDS
 //   K7 epilogue              : state flush + end mark + size/overflow
 #include "fqgpu_internal.h"
