@@ -503,7 +503,7 @@ __device__ __forceinline__ unsigned reset_state(const LdsCTable &t, unsigned sym
 // builds it once per handle).  Exact by construction: no speculation, nothing to verify.
 constexpr unsigned SETS_WAVES = 8;          // segments (waves) per workgroup in step A, one-symbol table
 constexpr unsigned SETS_WAVES2 = 16;        // ... with the 64 KB two-symbol table (one workgroup per CU)
-constexpr unsigned SETS_ROUNDS = 2;         // a workgroup owns WAVES * SETS_ROUNDS segments, handed out to its waves one by one
+constexpr unsigned SETS_ROUNDS = 4;         // a workgroup owns WAVES * SETS_ROUNDS segments, handed out to its waves one by one
 constexpr unsigned SETS_MAX_CLASSES = 512;  // above this a segment keeps carrying every state
 constexpr unsigned SETS_BLOCK = 1024;       // symbols per 16-byte-per-lane load; S is a multiple
 
