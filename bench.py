@@ -209,7 +209,20 @@ def main():
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+    # the same kernel's average duration in the committed rocprofv3 summary (first wave to last
+    # wave; the HIP-event span above also contains the time the launch waits for free CUs when
+    # four blocks are in flight)
+    rocprof_avg_ms = None
+    try:
+        import csv
+        with open(os.path.join(ROOT, "profiles", "r01_bench_encode_kernel_stats.csv")) as fh:
+            for row in csv.DictReader(fh):
+                if tj.get("kernel") == dom[0] and tj.get("rocprof_kernel", "").split(" ")[0] in row["Name"]:
+                    rocprof_avg_ms = round(float(row["AverageNs"]) / 1e6, 4)
+                    break
+    except Exception:
+        rocprof_avg_ms = None
+    roofline = {"bound": "hbm", "kernel": dom[0], "rocprof_avg_launch_ms": rocprof_avg_ms, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                 "avg_launch_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(alg_dom),
                 "launches_timed": calls.get(dom[0], 0),

@@ -1772,7 +1772,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                          fq_debug_no_sym(M::STREAM));
   }
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.scan" : (serial_seq ? "seq.setfunc" : "seq.scan"));  dbg_off = (dbg_mask & 8u) != 0;
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.scan" : (serial_seq ? "seq.plan" : "seq.scan"));  dbg_off = (dbg_mask & 8u) != 0;
   if (serial_seq) {
     uint32_t *plan = sc.seq_plan.as<uint32_t>();
     uint16_t *entry = reinterpret_cast<uint16_t *>(plan + SEGPLAN_WORDS);
@@ -1783,6 +1783,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     const unsigned max_fitems = seq_max_segs / (wpg * SETS_ROUNDS) + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
     static const bool dbg_skip = getenv("FQGPU_DEBUG_SKIP_SEQ_CHAIN") != nullptr;  // timing experiment only: wrong output
     if (!dbg_off) hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, wpg * SETS_ROUNDS, plan);
+    FQ_SPAN_END();
+    FQ_SPAN_BEGIN("seq.setfunc");
     if (!dbg_skip) {
       if (dbg_off) {
       } else if (two)

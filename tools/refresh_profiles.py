@@ -31,7 +31,7 @@ skip = ("k_hist", "k_build", "k_normalize", "k_fill", "k_log", "k_reset", "k_pro
 print("HBM MB per block:", sum(o[4] * o[1] for o in out if not o[0].startswith(skip)) / 8)
 for o in out[:12]: print("%-36s x%3d total(f x2) %8.1f MB  (fetch raw %7.1f write %7.1f)" % (o[0][:36], o[1], o[4], o[2] * 1.024 / 1e3, o[3] * 1.024 / 1e3))
 sf = [o for o in out if o[0].startswith("k_seq_setfunc")][0]
-json.dump({"kernel": "seq.setfunc", "rocprof_kernel": sf[0] + " (the seq.setfunc span also covers k_seq_segplan)", "fetch_size_kb": round(sf[2], 1), "write_size_kb": round(sf[3], 1),
+json.dump({"kernel": "seq.setfunc", "rocprof_kernel": sf[0], "fetch_size_kb": round(sf[2], 1), "write_size_kb": round(sf[3], 1),
            "traffic_bytes_per_launch": int((2 * sf[2] + sf[3]) * 1024),
            "note": "separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --steps 1 --warmup 1 --skip-cpu --skip-decode (256 MiB blocks); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads)"},
           open(R + "profiles/r01_traffic.json", "w"), indent=1)
