@@ -18,7 +18,9 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <istream>
 #include <memory>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <string_view>
@@ -76,17 +78,51 @@ inline void fqgpuCheck(int rc, const char *what) {
 
 /** FreqTable PODs exactly as the archive stores them (src/fse_common.hpp:147-174) */
 struct DatasetMeta {
+  /** used by the host's header coder for delta-ing the first header of each chunk (src/prepare.h:30) */
+  std::string first_header;
   std::unique_ptr<std::byte[]> ft_seq{new std::byte[FQGPU_SEQ_FT_BYTES]};
   std::unique_ptr<std::byte[]> ft_qual{new std::byte[FQGPU_QUAL_FT_BYTES]};
   DatasetMeta() = default;
+  explicit DatasetMeta(std::string_view header) : first_header(header) {}
   /** DatasetMeta(const FastqChunk&) (src/prepare.h:23-27): dataset analysis on the GPU */
-  explicit DatasetMeta(const FastqChunk &chunk, int device = 0) {
+  explicit DatasetMeta(const FastqChunk &chunk, int device = 0)
+      : first_header(chunk.records.empty() ? std::string_view() : chunk.records.front().header()) {
     std::vector<fqgpu_rec> recs = toRecordTable(chunk);
     fqgpuCheck(fqgpu_freq_tables(device, reinterpret_cast<const uint8_t *>(chunk.raw_data.data()),
                                  chunk.raw_data.size(), recs.data(), recs.size(), ft_seq.get(),
                                  ft_qual.get(), nullptr, nullptr),
                "calculateFreqTable");
   }
+  /** bytes of the metadata section of an archive (src/prepare.h:44-52) */
+  [[nodiscard]] std::size_t size() const { return sizeof(readlen_t) + first_header.length() + FQGPU_SEQ_FT_BYTES + FQGPU_QUAL_FT_BYTES; }
+
+  /** DatasetMeta::storeToStream (src/prepare.cpp:12-21), byte for byte: u16 header length, the
+   *  header, then the two FreqTable PODs as they lie in memory */
+  static void storeToStream(const DatasetMeta &meta, std::ostream &os) {
+    if (meta.first_header.size() > 0xFFFFu) throw std::invalid_argument("first header longer than a readlen_t");
+    const readlen_t hlen = static_cast<readlen_t>(meta.first_header.size());
+    os.write(reinterpret_cast<const char *>(&hlen), sizeof(hlen));
+    os.write(meta.first_header.data(), hlen);
+    os.write(reinterpret_cast<const char *>(meta.ft_seq.get()), FQGPU_SEQ_FT_BYTES);
+    os.write(reinterpret_cast<const char *>(meta.ft_qual.get()), FQGPU_QUAL_FT_BYTES);
+  }
+  /** DatasetMeta::loadFromStream (src/prepare.cpp:23-41) */
+  static DatasetMeta loadFromStream(std::istream &is) {
+    readlen_t hlen = 0;
+    is.read(reinterpret_cast<char *>(&hlen), sizeof(hlen));
+    std::string header(hlen, '!');
+    is.read(header.data(), hlen);
+    DatasetMeta meta{std::string_view(header)};
+    is.read(reinterpret_cast<char *>(meta.ft_seq.get()), FQGPU_SEQ_FT_BYTES);
+    is.read(reinterpret_cast<char *>(meta.ft_qual.get()), FQGPU_QUAL_FT_BYTES);
+    if (!is.good()) throw std::runtime_error("truncated dataset metadata");
+    return meta;
+  }
+  friend bool operator==(const DatasetMeta &a, const DatasetMeta &b) {
+    return a.first_header == b.first_header && std::memcmp(a.ft_seq.get(), b.ft_seq.get(), FQGPU_SEQ_FT_BYTES) == 0 &&
+           std::memcmp(a.ft_qual.get(), b.ft_qual.get(), FQGPU_QUAL_FT_BYTES) == 0;
+  }
+
   static std::vector<fqgpu_rec> toRecordTable(const FastqChunk &chunk) {
     std::vector<fqgpu_rec> recs(chunk.records.size());
     const char *base = chunk.raw_data.data();

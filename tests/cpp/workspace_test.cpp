@@ -5,6 +5,7 @@
 #include "../../fqcomp28_amd/csrc/workspace.hpp"
 
 #include <cstdio>
+#include <sstream>
 #include <fstream>
 #include <iterator>
 
@@ -70,6 +71,23 @@ static int encodeChunkRoundTrip(const char *path) {
     CHECK(ref.records[i].qual() == chunk_out.records[i].qual());
   }
   CHECK(chunk_out.raw_data == original);
+
+  // DatasetMeta store/load (reference test/prepare_test.cpp): u16 length + first header + the two
+  // FreqTable PODs, round trip and exact size
+  {
+    std::stringstream ss;
+    DatasetMeta::storeToStream(meta, ss);
+    const std::string bytes = ss.str();
+    CHECK(bytes.size() == meta.size());
+    CHECK(bytes.size() == 2 + meta.first_header.size() + 3076 + 1081348);
+    CHECK(meta.first_header == ref.records.front().header());
+    readlen_t hlen = 0;
+    std::memcpy(&hlen, bytes.data(), 2);
+    CHECK(hlen == meta.first_header.size());
+    CHECK(std::memcmp(bytes.data() + 2 + hlen, meta.ft_seq.get(), 3076) == 0);
+    const DatasetMeta back = DatasetMeta::loadFromStream(ss);
+    CHECK(back == meta);
+  }
   std::printf("ok %s: %zu records, seq %zu B, qual %zu B\n", path, ref.records.size(), src.seq.size(),
               src.qual.size());
   return 0;
