@@ -157,6 +157,44 @@ def test_chain_parameters_never_change_the_bits(F, golden_dir, seg, seq_generic,
     ctx.close()
 
 
+def _fastq_with_lengths(lengths, seed=3):
+    rng = np.random.default_rng(seed)
+    parts = []
+    for i, L in enumerate(lengths):
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L)]
+        if L > 20:
+            seq[rng.integers(0, L, size=max(1, L // 200))] = ord("N")
+        q = np.clip(np.rint(rng.normal(30, 6, size=L)), 2, 41).astype(np.uint8) + 33
+        parts.append(b"@r%d\n" % i + seq.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    raw = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    return raw, O.parse_fastq(raw)
+
+
+@pytest.mark.parametrize("case", ["min_length_3", "max_length_65535", "mixed_extremes"])
+def test_extreme_read_lengths(F, case):
+    """Reads of the minimum (3) and maximum (65535 = readlen_t) length and a mix of both: the
+    record walker's 64-record windows cover anything from 192 symbols to several tiles."""
+    if case == "min_length_3":
+        lengths = [3] * 60000
+    elif case == "max_length_65535":
+        lengths = [65535] * 12
+    else:
+        lengths = ([3, 4, 5, 65535, 7, 150, 3] * 40) + [65535, 3, 3, 3, 30000]
+    raw, recs = _fastq_with_lengths(lengths)
+    assert list(recs["len"]) == lengths
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    g = ctx.encode_block(raw, recs, flags=1)
+    assert_same_encoding(g, e)
+    db = ctx.dblock(raw)  # GPU record parser on the same bytes
+    assert np.array_equal(db.records(), recs)
+    db.close()
+    rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
 def test_partition_fallback_without_lane_ordered_lds_atomics(F, golden_dir, monkeypatch):
     """The partition kernels rank with lane-ordered LDS atomics when the handle's probe confirms the
     ordering; FQGPU_NO_LDS_ATOMIC_RANK forces the ballot-match kernels a device without that
