@@ -1339,7 +1339,7 @@ k_bitcount(const uint32_t *__restrict__ slot_of, const uint16_t *__restrict__ ou
 //   K6a k_bitcount_seq  reads the batch's 256 runs of (nb, bits) with consecutive lanes on
 //                       consecutive slots into LDS and picks every symbol's value there by lpos16
 // slot_of (4 bytes per symbol) is not needed for this stream.
-constexpr unsigned SEQ_BATCH = PACK_TILE;  // one partition batch = one packing tile
+constexpr unsigned SEQ_BATCH = PACK_TILE;  // one partition batch = one packing tile (two were measured: no gain)
 
 struct SeqBatchDesc {
   uint32_t *start;  // [batches][256] global slot of the first symbol of context c in this batch
@@ -1454,11 +1454,11 @@ k_bitcount_seq(const uint16_t *__restrict__ lpos16, SeqBatchDesc bd, const uint1
   __shared__ uint16_t pre[B + 2];
   __shared__ uint16_t vals[SEQ_BATCH];
   __shared__ unsigned wsum[PACK_THREADS / 64];
-  const unsigned ptile = fq_xcd_tile(blockIdx.x, gridDim.x);
-  const unsigned b0 = ptile * PACK_TILE, nb = min((unsigned)PACK_TILE, n_sym - b0);
+  const unsigned gb = fq_xcd_tile(blockIdx.x, gridDim.x);  // batch
+  const unsigned b0 = gb * SEQ_BATCH, nb = min((unsigned)SEQ_BATCH, n_sym - b0);
   static_assert(PACK_THREADS == B, "one thread per context loads the batch descriptor");
-  start[threadIdx.x] = bd.start[(size_t)ptile * B + threadIdx.x];
-  pre[threadIdx.x] = bd.pre[(size_t)ptile * B + threadIdx.x];
+  start[threadIdx.x] = bd.start[(size_t)gb * B + threadIdx.x];
+  pre[threadIdx.x] = bd.pre[(size_t)gb * B + threadIdx.x];
   __syncthreads();
   // the batch's runs of (nb, bits): consecutive threads on consecutive slots of a run
   for (unsigned p = threadIdx.x; p < nb; p += PACK_THREADS) {
@@ -1471,36 +1471,41 @@ k_bitcount_seq(const uint16_t *__restrict__ lpos16, SeqBatchDesc bd, const uint1
     vals[p] = out16[start[lo] + (p - (unsigned)pre[lo])];
   }
   __syncthreads();
-  const unsigned e0 = b0 + threadIdx.x * PACK_PER_THREAD;
-  unsigned bits = 0;
-  unsigned v[PACK_PER_THREAD];
-  {
-    const uint4 *l4 = reinterpret_cast<const uint4 *>(lpos16 + e0);
+  for (unsigned pt = 0; pt < SEQ_BATCH / PACK_TILE; pt++) {  // the packing tiles of the batch
+    const unsigned t0 = b0 + pt * PACK_TILE;
+    if (t0 >= n_sym) break;
+    const unsigned e0 = t0 + threadIdx.x * PACK_PER_THREAD;
+    unsigned bits = 0;
+    unsigned v[PACK_PER_THREAD];
+    {
+      const uint4 *l4 = reinterpret_cast<const uint4 *>(lpos16 + e0);
 #pragma unroll
-    for (unsigned i = 0; i < PACK_PER_THREAD / 8; i++) {
-      const uint4 t = e0 < n_sym ? l4[i] : make_uint4(0, 0, 0, 0);
-      const unsigned w[4] = {t.x, t.y, t.z, t.w};
+      for (unsigned i = 0; i < PACK_PER_THREAD / 8; i++) {
+        const uint4 t = e0 < n_sym ? l4[i] : make_uint4(0, 0, 0, 0);
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-      for (unsigned j = 0; j < 8; j++) {
-        const unsigned lp = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-        v[8 * i + j] = e0 + 8 * i + j < n_sym ? (unsigned)vals[lp] : 0u;
-        bits += v[8 * i + j] >> 12;
+        for (unsigned j = 0; j < 8; j++) {
+          const unsigned lp = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+          v[8 * i + j] = e0 + 8 * i + j < n_sym ? (unsigned)vals[lp] : 0u;
+          bits += v[8 * i + j] >> 12;
+        }
       }
     }
-  }
-  if (e0 < n_sym) {
-    uint4 *o4 = reinterpret_cast<uint4 *>(enc16 + e0);
-    o4[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-    o4[1] = make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), v[12] | (v[13] << 16), v[14] | (v[15] << 16));
-  }
+    if (e0 < n_sym) {
+      uint4 *o4 = reinterpret_cast<uint4 *>(enc16 + e0);
+      o4[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+      o4[1] = make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), v[12] | (v[13] << 16), v[14] | (v[15] << 16));
+    }
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) bits += __shfl_xor(bits, d);
-  if (fq_lane() == 0) wsum[threadIdx.x >> 6] = bits;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned tot = 0;
-    for (unsigned i = 0; i < PACK_THREADS / 64; i++) tot += wsum[i];
-    tile_bits[ptile] = tot;
+    for (int d = 32; d > 0; d >>= 1) bits += __shfl_xor(bits, d);
+    __syncthreads();  // wsum of the previous tile has been read
+    if (fq_lane() == 0) wsum[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned tot = 0;
+      for (unsigned i = 0; i < PACK_THREADS / 64; i++) tot += wsum[i];
+      tile_bits[t0 / PACK_TILE] = tot;
+    }
   }
 }
 
@@ -1696,7 +1701,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   bool dbg_off = false;
   // keys: ckey u16 | csym u8 (quality), later enc16 u16 over both;  slot_of: u32 -- padded by one batch
   const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15;  // keeps every sub-array 16-byte aligned
-  static_assert(TILE_SEQ % PACK_TILE == 0 && TILE_QUAL % PACK_TILE == 0, "a packing tile lies inside one partition tile");
+  static_assert(TILE_SEQ % SEQ_BATCH == 0 && SEQ_BATCH % PACK_TILE == 0 && TILE_QUAL % PACK_TILE == 0, "a packing tile lies inside one partition tile");
   if ((rc = sc.slot_of.reserve(n_pad * 4))) return rc;
   if ((rc = sc.keys.reserve(n_pad * 3))) return rc;
   if ((rc = sc.sorted_sym.reserve(padded))) return rc;
@@ -1851,7 +1856,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.bitcount" : "seq.bitcount");  dbg_off = (dbg_mask & 16u) != 0;
   if (!dbg_off && serial_seq)
-    hipLaunchKernelGGL(k_bitcount_seq, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, lpos16, bd, sc.out16.as<uint16_t>(), n_sym,
+    hipLaunchKernelGGL(k_bitcount_seq, dim3((n_sym + SEQ_BATCH - 1) / SEQ_BATCH), dim3(PACK_THREADS), 0, st, lpos16, bd, sc.out16.as<uint16_t>(), n_sym,
                        sc.tile_bits.as<uint32_t>(), enc16);
   else if (!dbg_off)
     hipLaunchKernelGGL(k_bitcount, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, sc.slot_of.as<uint32_t>(),
