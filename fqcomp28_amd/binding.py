@@ -19,6 +19,7 @@ QUAL_FT_DTYPE = np.dtype(
     [("norm", "<i2", (QUAL_MODELS, QUAL_ALPHA)), ("logs", "<u4", (QUAL_MODELS,)), ("max_log", "<u4")]
 )
 F_WRITE_BACK_N = 1
+F_DECODE_INDEX = 2  # extension: the encode also leaves a decode index per stream
 
 ERRORS = {0: "OK", -1: "OVERFLOW", -2: "SHORT_READ", -3: "CORRUPT", -4: "ARG", -5: "NO_DEVICE",
           -6: "NOMEM", -7: "HIP"}
@@ -85,6 +86,10 @@ _PROTOS = {
     "fqgpu_dblock_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fqgpu_dblock_longest_chain": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "fqgpu_ctx_set_index_stride": (C.c_int, [C.c_void_p, C.c_uint]),
+    "fqgpu_dblock_index_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    "fqgpu_dblock_fetch_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "fqgpu_dblock_load_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "fqgpu_ctx_set_lanes": (C.c_int, [C.c_void_p, C.c_uint]),
     "fqgpu_ctx_set_seq_segment": (C.c_int, [C.c_void_p, C.c_uint]),
     "fqgpu_dblock_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -211,6 +216,19 @@ class DBlock:
     def encode(self, flags=0):
         _check(lib().fqgpu_dblock_encode(self.ctx.h, self.h, flags), "dblock_encode")
 
+    def fetch_index(self, stream):
+        """decode index of one stream (0 = sequence, 1 = quality) of the last encode with F_DECODE_INDEX"""
+        n = C.c_size_t(0)
+        _check(lib().fqgpu_dblock_index_bytes(self.h, stream, C.byref(n)), "dblock_index_bytes")
+        out = np.zeros(n.value, dtype=np.uint8)
+        if n.value:
+            _check(lib().fqgpu_dblock_fetch_index(self.ctx.h, self.h, stream, _p(out), out.size), "dblock_fetch_index")
+        return out
+
+    def load_index(self, stream, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        return lib().fqgpu_dblock_load_index(self.ctx.h, self.h, stream, _p(data) if data.size else None, data.size)
+
     def wipe(self):
         _check(lib().fqgpu_dblock_wipe(self.ctx.h, self.h), "dblock_wipe")
 
@@ -277,6 +295,9 @@ class Context:
         if seq_segment is not None:
             _check(lib().fqgpu_ctx_set_seq_segment(self.h, seq_segment), "set_seq_segment")
         _check(lib().fqgpu_ctx_set_chain_params(self.h, segment, flags), "set_chain_params")
+
+    def set_index_stride(self, symbols):
+        _check(lib().fqgpu_ctx_set_index_stride(self.h, symbols), "set_index_stride")
 
     def set_lanes(self, lanes):
         _check(lib().fqgpu_ctx_set_lanes(self.h, lanes), "set_lanes")

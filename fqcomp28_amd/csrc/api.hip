@@ -354,7 +354,7 @@ extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
   (void)fqgpu_sync(ctx);
   free_tables(ctx->tab[0]);
   free_tables(ctx->tab[1]);
-  DevBuf *bufs[] = {&ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc};
+  DevBuf *bufs[] = {&ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc, &ctx->dec_chunks, &ctx->dec_recstart};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < FQ_MAX_LANES; i++) free_lane(ctx->lanes[i]);
   if (ctx->hp_block) fqgpu_dblock_destroy(ctx->hp_block);
@@ -379,6 +379,50 @@ extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsi
 extern "C" int fqgpu_ctx_set_seq_segment(fqgpu_ctx *ctx, unsigned symbols) {
   if (!ctx) return FQGPU_E_ARG;
   ctx->seq_segment = symbols;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_ctx_set_index_stride(fqgpu_ctx *ctx, unsigned symbols) {
+  if (!ctx || symbols == 0 || symbols > (1u << 30)) return FQGPU_E_ARG;
+  ctx->index_stride = (symbols + 65535u) & ~65535u;  // whole partition tiles of both streams
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_index_bytes(const fqgpu_dblock *b, int stream, size_t *bytes) {
+  if (!b || !bytes || stream < 0 || stream > 1) return FQGPU_E_ARG;
+  *bytes = b->index_bytes[stream];
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_fetch_index(fqgpu_ctx *ctx, const fqgpu_dblock *b, int stream, void *out, size_t cap) {
+  if (!ctx || !b || !out || stream < 0 || stream > 1 || cap < b->index_bytes[stream]) return FQGPU_E_ARG;
+  int rc = fqgpu_sync(ctx);
+  if (rc) return rc;
+  if (b->index_bytes[stream]) FQ_HIP(hipMemcpy(out, b->index[stream], b->index_bytes[stream], hipMemcpyDeviceToHost));
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_load_index(fqgpu_ctx *ctx, fqgpu_dblock *b, int stream, const void *data, size_t len) {
+  if (!ctx || !b || stream < 0 || stream > 1 || (!data && len)) return FQGPU_E_ARG;
+  int rc = fqgpu_sync(ctx);
+  if (rc) return rc;
+  if (len == 0) { b->index_bytes[stream] = 0; return FQGPU_OK; }
+  const unsigned B = stream ? FQGPU_QUAL_MODELS : FQGPU_SEQ_MODELS;
+  FqIndexHeader h;
+  if (len < sizeof(h)) return FQGPU_E_CORRUPT;
+  memcpy(&h, data, sizeof(h));
+  if (h.magic != FQ_INDEX_MAGIC || h.stream != (uint32_t)stream || h.stride == 0 || (h.stride & 65535u) ||
+      h.n_sym != b->n_bases || h.n_snap != (h.n_sym ? (uint32_t)((h.n_sym - 1) / h.stride) : 0u) ||
+      len != sizeof(h) + (size_t)h.n_snap * fq_index_snap_bytes(B))
+    return FQGPU_E_CORRUPT;
+  if (len > b->index_cap[stream]) {
+    if (b->index[stream]) (void)hipFree(b->index[stream]);
+    b->index[stream] = fq_dev_alloc<uint8_t>(len + 64);
+    b->index_cap[stream] = b->index[stream] ? len : 0;
+    if (!b->index[stream]) return FQGPU_E_NOMEM;
+  }
+  FQ_HIP(hipMemcpy(b->index[stream], data, len, hipMemcpyHostToDevice));
+  b->index_bytes[stream] = len;
   return FQGPU_OK;
 }
 
@@ -419,7 +463,7 @@ extern "C" int fqgpu_ctx_dump_tables(fqgpu_ctx *ctx, int stream, unsigned model,
 extern "C" void fqgpu_dblock_destroy(fqgpu_dblock *b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  void *ps[] = {b->raw, b->recs, b->seq, b->qual, b->readlens, b->n_count, b->n_pos, b->result};
+  void *ps[] = {b->raw, b->recs, b->seq, b->qual, b->readlens, b->n_count, b->n_pos, b->result, b->index[0], b->index[1]};
   for (void *p : ps) if (p) (void)hipFree(p);
   delete b;
 }
@@ -634,6 +678,7 @@ extern "C" int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const 
   FQ_HIP(hipMemcpy(b->n_count, n_count, b->n_recs * 2, hipMemcpyHostToDevice));
   if (n_pos_len) FQ_HIP(hipMemcpy(b->n_pos, n_pos, n_pos_len * 2, hipMemcpyHostToDevice));
   b->seq_len = seq_len; b->qual_len = qual_len; b->n_pos_len = n_pos_len;
+  b->index_bytes[0] = b->index_bytes[1] = 0;  // an index belongs to the streams it was made for
   return FQGPU_OK;
 }
 
@@ -686,6 +731,7 @@ static int hp_block_acquire(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_
   b->raw_len = raw_len; b->n_recs = n_recs; b->n_bases = n_bases;
   b->seq_cap = seq_cap; b->qual_cap = qual_cap; b->n_pos_cap = n_pos_cap;
   b->seq_len = b->qual_len = b->n_pos_len = 0;
+  b->index_bytes[0] = b->index_bytes[1] = 0;
   b->last_op = 0;
   memset(&b->host_result, 0, sizeof(b->host_result));
   *out = b;

@@ -12,6 +12,8 @@
 // from the table logs).  All blocks of a batch are decoded by ONE launch.
 #include "fqgpu_internal.h"
 
+#include <vector>
+
 namespace {
 
 struct DecJob {
@@ -23,6 +25,13 @@ struct DecJob {
   uint8_t *raw;
   BlockResult *res;
   unsigned rec_base;  // first index of this block in the batch-wide record arrays
+  // decode index (extension): both present -> one lane per (stream, stride) instead of one per stream
+  const uint8_t *index[2];
+  const uint32_t *rec_start;  // [n_recs + 1] encode index of the first symbol of every record
+};
+
+struct DecChunk {
+  unsigned job, stream, chunk;
 };
 
 // Pointers read out of the job descriptors are generic to the compiler, which then emits
@@ -135,6 +144,131 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *sta
   res->total_bits = (unsigned long long)(p0 - (long long)sum_logs);
 }
 
+// One stride of one stream, started from a snapshot of the decode index (or from the end of the
+// stream for the last stride): encode indices [e_lo, e_hi) in decoder order, i.e. from the record
+// and position of symbol e_hi - 1 towards the front of the block.
+template <class M>
+__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, uint16_t *state, uint32_t *dt_off) {
+  constexpr unsigned B = M::B;
+  const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
+  const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
+  StreamResult *res = &j.res->s[M::STREAM];
+  const unsigned lane = threadIdx.x;
+  g_cu32 *w = (g_cu32 *)reinterpret_cast<const uint32_t *>(src);
+  g_crec *recs = (g_crec *)j.recs;
+  g_cu32 *rec_start = (g_cu32 *)j.rec_start;
+  g_u8 *raw = (g_u8 *)j.raw;
+  const FqIndexHeader hdr = *reinterpret_cast<const FqIndexHeader *>(j.index[M::STREAM]);
+  const size_t snap_bytes = FQ_INDEX_SNAP_HEAD + 2 * (size_t)B;
+  const uint8_t *snaps = j.index[M::STREAM] + sizeof(FqIndexHeader);
+  const unsigned n_sym = (unsigned)hdr.n_sym, stride = hdr.stride;
+  const unsigned e_lo = chunk * stride, e_hi = min(e_lo + stride, n_sym);
+  const bool from_end = chunk == hdr.n_snap;  // the last stride starts at the stream's end mark
+
+  long long pos;
+  unsigned prev = 0xFFFFFFFFu;
+  if (from_end) {
+    const unsigned last = len ? src[len - 1] : 0u;
+    if (last == 0) { if (lane == 0) res->corrupt = 1; return; }
+    const long long p0 = (long long)(len - 1) * 8 + (31 - __clz((int)last));
+    const unsigned sum_logs = tab.log_prefix[B];
+    if (p0 < (long long)sum_logs) { if (lane == 0) res->corrupt = 1; return; }
+    for (unsigned c = lane; c < B; c += 64) {
+      const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
+      state[c] = (uint16_t)peek_bits(w, lo, tab.logs[c]);
+      dt_off[c] = tab.dt_off[c] + 1u;
+    }
+    pos = p0 - (long long)sum_logs;
+    if (lane == 0) res->total_bits = (unsigned long long)pos;
+  } else {
+    const uint8_t *snap = snaps + (size_t)chunk * snap_bytes;  // snapshot chunk + 1 sits at e_hi
+    const uint16_t *st = reinterpret_cast<const uint16_t *>(snap + FQ_INDEX_SNAP_HEAD);
+    for (unsigned c = lane; c < B; c += 64) {
+      state[c] = st[c];
+      dt_off[c] = tab.dt_off[c] + 1u;
+    }
+    pos = (long long)*reinterpret_cast<const unsigned long long *>(snap);
+    prev = reinterpret_cast<const uint32_t *>(snap)[2];
+    if (pos > (long long)len * 8) { if (lane == 0) res->corrupt = 1; return; }
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  // every bit of this stride consumed, none invented: the walk must end where the previous
+  // snapshot (or the start of the stream) says
+  const long long pos_end = chunk == 0 ? 0ll : (long long)*reinterpret_cast<const unsigned long long *>(snaps + (size_t)(chunk - 1) * snap_bytes);
+
+  BitReader br;
+  br.w = w;
+  br.pos = pos;
+  br.refill();
+  const uint32_t *__restrict__ dt = tab.dt;
+  unsigned r = fq_locate((const uint32_t *)j.rec_start, 0, j.n_recs - 1, e_hi - 1);  // record of symbol e_hi - 1
+  bool first = true;
+  for (;;) {
+    const unsigned rs = rec_start[r];
+    fqgpu_rec rec;
+    rec.seq_off = recs[r].seq_off; rec.qual_off = recs[r].qual_off; rec.len = recs[r].len;
+    // positions of this record inside [e_lo, e_hi): encode index of position i is rs + len - 1 - i
+    const unsigned i0 = first ? rec.len - 1u - (e_hi - 1u - rs) : 0u;
+    const unsigned i1 = rs >= e_lo ? rec.len : rec.len - (e_lo - rs);  // one past the last position
+    if (M::STREAM == 0) {
+      g_u8 *out = raw + rec.seq_off;
+      unsigned ctx = 0xD7u;  // FSE_Sequence::INITIAL_CONTEXT
+      if (first && !from_end)
+        for (int b = 3; b >= 0; b--) {
+          const unsigned ch = (prev >> (8 * b)) & 0xFFu;
+          if (ch != 0xFFu) ctx = (ctx >> 2) + (fq_base_code(ch) << 6);
+        }
+      for (unsigned i = i0; i < i1; i++) {
+        const uint32_t e = dt[dt_off[ctx] + state[ctx]];
+        const unsigned sym = (e >> 16) & 3u;
+        state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
+        out[i] = (uint8_t)(0x54474341u >> (8u * sym));
+        ctx = (ctx >> 2) + (sym << 6);
+      }
+    } else {
+      g_u8 *out = raw + rec.qual_off;
+      unsigned ctx = 1u << 12, q1 = 0, q2 = 0;  // calcContext(0,0,0)
+      if (first && !from_end) {
+        const unsigned a = prev & 0xFFu, b = (prev >> 8) & 0xFFu, c = (prev >> 16) & 0xFFu;
+        const unsigned qa = a != 0xFFu ? (a - 33u) & 63u : 0u, qb = b != 0xFFu ? (b - 33u) & 63u : 0u,
+                       qc = c != 0xFFu ? (c - 33u) & 63u : 0u;
+        ctx = fq_qual_ctx(qa, qb, qc);
+        q1 = qa; q2 = qb;
+      }
+      for (unsigned i = i0; i < i1; i++) {
+        const uint32_t e = dt[dt_off[ctx] + state[ctx]];
+        const unsigned q = (e >> 16) & 63u;
+        state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
+        out[i] = (uint8_t)(q + 33u);
+        ctx = fq_qual_ctx(q, q1, q2);
+        q2 = q1;
+        q1 = q;
+      }
+    }
+    first = false;
+    if (br.pos < 0 || rs <= e_lo || r == 0) break;
+    r--;
+  }
+  if (br.pos != pos_end) res->corrupt = 1;
+}
+
+__global__ void __launch_bounds__(64)
+k_decode_chunks(const DecJob *__restrict__ jobs, const DecChunk *__restrict__ chunks, TabView seq_tab, TabView qual_tab) {
+  __shared__ uint16_t state[QualModel::B];
+  __shared__ uint32_t dt_off[QualModel::B];
+  const DecChunk ch = chunks[blockIdx.x];
+  if (ch.stream) decode_chunk<QualModel>(jobs[ch.job], ch.chunk, qual_tab, state, dt_off);
+  else decode_chunk<SeqModel>(jobs[ch.job], ch.chunk, seq_tab, state, dt_off);
+}
+
+// record lengths of one block, for the encode index of the first symbol of every record
+__global__ void __launch_bounds__(256)
+k_lens_of(const fqgpu_rec *__restrict__ recs, unsigned n, uint32_t *__restrict__ lens32) {
+  const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) lens32[r] = recs[r].len;
+}
+
 // grid = 2 * n_blocks: the quality streams (longer chains, MB-scale DTables) are
 // dispatched first, the sequence streams behind them
 __global__ void __launch_bounds__(64)
@@ -206,15 +340,28 @@ int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b) {
   return FQGPU_OK;
 }
 
-int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks) {
+int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks_in, size_t n_blocks) {
   hipStream_t st = ctx->stream;
   if (!n_blocks) return FQGPU_OK;
   int rcs = fqgpu_sync(ctx);  // blocks may still be in an encode lane
   if (rcs) return rcs;
-  // job descriptors: pinned host staging is not worth it for a few KB; plain async copy
-  // from a host vector that outlives the copy (we synchronise the copy right away)
-  DecJob *host = new DecJob[n_blocks];
-  size_t r_tot = 0, r_max = 0;
+  // blocks with a decode index (both streams, at least one snapshot) go to the chunk kernel, the
+  // others to the one-lane-per-stream kernel: plain blocks first in the job array
+  auto snaps_of = [](const fqgpu_dblock *b, int stream) -> size_t {
+    const size_t sb = fq_index_snap_bytes(stream ? FQGPU_QUAL_MODELS : FQGPU_SEQ_MODELS);
+    return b->index_bytes[stream] >= sizeof(FqIndexHeader) ? (b->index_bytes[stream] - sizeof(FqIndexHeader)) / sb : 0;
+  };
+  std::vector<fqgpu_dblock *> blocks;
+  blocks.reserve(n_blocks);
+  for (size_t i = 0; i < n_blocks; i++)
+    if (!(snaps_of(blocks_in[i], 0) && snaps_of(blocks_in[i], 1))) blocks.push_back(blocks_in[i]);
+  const size_t n_plain = blocks.size();
+  for (size_t i = 0; i < n_blocks; i++)
+    if (snaps_of(blocks_in[i], 0) && snaps_of(blocks_in[i], 1)) blocks.push_back(blocks_in[i]);
+
+  std::vector<DecJob> host(n_blocks);
+  std::vector<DecChunk> chunks;
+  size_t r_tot = 0, r_max = 0, rs_tot = 0;
   for (size_t i = 0; i < n_blocks; i++) {
     const fqgpu_dblock *b = blocks[i];
     DecJob &j = host[i];
@@ -226,16 +373,38 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_block
     j.raw = b->raw;
     j.res = b->result;
     j.rec_base = (unsigned)r_tot;
+    j.index[0] = j.index[1] = nullptr;
+    j.rec_start = nullptr;
     r_tot += b->n_recs;
     if (b->n_recs > r_max) r_max = b->n_recs;
+    if (i >= n_plain) rs_tot += b->n_recs + 1;
   }
   int rc;
-  if ((rc = ctx->dec_desc.reserve(n_blocks * sizeof(DecJob)))) { delete[] host; return rc; }
-  if ((rc = ctx->n_cnt32.reserve((r_tot + 1) * 4))) { delete[] host; return rc; }
-  if ((rc = ctx->n_off.reserve((r_tot + 1) * 4))) { delete[] host; return rc; }
-  hipError_t he = hipMemcpyAsync(ctx->dec_desc.p, host, n_blocks * sizeof(DecJob), hipMemcpyHostToDevice, st);
-  if (he == hipSuccess) he = hipStreamSynchronize(st);
-  delete[] host;
+  if ((rc = ctx->dec_desc.reserve(n_blocks * sizeof(DecJob)))) return rc;
+  if ((rc = ctx->n_cnt32.reserve((r_tot + 1) * 4))) return rc;
+  if ((rc = ctx->n_off.reserve((r_tot + 1) * 4))) return rc;
+  if (n_plain < n_blocks) {
+    if ((rc = ctx->dec_recstart.reserve(rs_tot * 4 + 64))) return rc;
+    size_t at = 0;
+    for (size_t i = n_plain; i < n_blocks; i++) {
+      const fqgpu_dblock *b = blocks[i];
+      DecJob &j = host[i];
+      j.index[0] = b->index[0]; j.index[1] = b->index[1];
+      uint32_t *rs = ctx->dec_recstart.as<uint32_t>() + at;
+      j.rec_start = rs;
+      at += b->n_recs + 1;
+      // lengths -> n_cnt32 (free until the N pass), exclusive scan -> rec_start
+      hipLaunchKernelGGL(k_lens_of, dim3((unsigned)((b->n_recs + 255) / 256)), dim3(256), 0, st, b->recs, (unsigned)b->n_recs,
+                         ctx->n_cnt32.as<uint32_t>());
+      if ((rc = fq_scan_u32_to_u32(st, ctx->n_cnt32.as<uint32_t>(), b->n_recs, rs, ctx->scan_tmp))) return rc;
+      for (int s = 1; s >= 0; s--)  // quality strides first: they are the longer ones
+        for (size_t k = snaps_of(b, s) + 1; k-- > 0;) chunks.push_back(DecChunk{(unsigned)i, (unsigned)s, (unsigned)k});
+    }
+    if ((rc = ctx->dec_chunks.reserve(chunks.size() * sizeof(DecChunk)))) return rc;
+    FQ_HIP(hipMemcpyAsync(ctx->dec_chunks.p, chunks.data(), chunks.size() * sizeof(DecChunk), hipMemcpyHostToDevice, st));
+  }
+  hipError_t he = hipMemcpyAsync(ctx->dec_desc.p, host.data(), n_blocks * sizeof(DecJob), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);  // the host vectors die with this call
   if (he != hipSuccess) return fq_hip_error(he, __FILE__, __LINE__);
   const DecJob *jobs = ctx->dec_desc.as<DecJob>();
 
@@ -244,7 +413,10 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_block
   TabView ts = {ctx->tab[0].logs, ctx->tab[0].log_prefix, ctx->tab[0].dt, ctx->tab[0].dt_off};
   TabView tq = {ctx->tab[1].logs, ctx->tab[1].log_prefix, ctx->tab[1].dt, ctx->tab[1].dt_off};
   fq_timer_span_begin(ctx, "decode", st);
-  hipLaunchKernelGGL(k_decode, dim3((unsigned)(2 * n_blocks)), dim3(64), 0, st, jobs, (unsigned)n_blocks, ts, tq);
+  if (n_plain)
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)(2 * n_plain)), dim3(64), 0, st, jobs, (unsigned)n_plain, ts, tq);
+  if (!chunks.empty())
+    hipLaunchKernelGGL(k_decode_chunks, dim3((unsigned)chunks.size()), dim3(64), 0, st, jobs, ctx->dec_chunks.as<DecChunk>(), ts, tq);
   fq_timer_span_end(ctx, st);
   fq_timer_span_begin(ctx, "npatch", st);
   const unsigned gx = (unsigned)min((r_max + 255) / 256, (size_t)4096);

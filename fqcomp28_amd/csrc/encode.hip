@@ -1509,6 +1509,76 @@ k_bitcount_seq(const uint16_t *__restrict__ lpos16, SeqBatchDesc bd, const uint1
   }
 }
 
+// ---- decode index (extension, include/fqgpu.h FQGPU_F_DECODE_INDEX) ------------------------
+// Snapshot k sits at encode index e = k * stride (a multiple of both partition tile sizes).
+// k_index_meta: bit position (= bit offset of packing tile e / 4096), the bytes in front of
+// symbol e - 1 in its record.  k_index_states: the state of every context at that point = the
+// state in front of the context's first symbol at or behind e, found by walking from the entry
+// state of the segment that holds it (at most one segment); one lane per (context, snapshot),
+// the context's CTable in LDS.
+template <class M>
+__global__ void __launch_bounds__(256)
+k_index_meta(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
+             const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned stride,
+             const unsigned long long *__restrict__ tile_bit_base, uint8_t *__restrict__ index) {
+  const unsigned n_snap = n_sym ? (n_sym - 1) / stride : 0u;
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;  // 0: header, 1 .. n_snap: snapshots
+  if (k == 0) {
+    FqIndexHeader h;
+    h.magic = FQ_INDEX_MAGIC; h.stream = M::STREAM; h.stride = stride; h.n_snap = n_snap;
+    h.n_sym = n_sym; h.reserved = 0;
+    *reinterpret_cast<FqIndexHeader *>(index) = h;
+    return;
+  }
+  if (k > n_snap) return;
+  const unsigned e = k * stride;
+  uint8_t *snap = index + sizeof(FqIndexHeader) + (size_t)(k - 1) * (FQ_INDEX_SNAP_HEAD + 2 * (size_t)M::B);
+  *reinterpret_cast<unsigned long long *>(snap) = tile_bit_base[e / PACK_TILE];
+  // symbol e - 1: record r, position p (encode order walks a record from its last position)
+  const unsigned r = fq_locate(rec_start, 0, R - 1, e - 1);
+  const fqgpu_rec rec = recs[r];
+  const unsigned p = rec.len - 1u - (e - 1u - rec_start[r]);
+  const uint8_t *line = raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off);
+  unsigned packed = 0;
+  for (unsigned i = 0; i < 4; i++) packed |= (p >= i + 1 ? (unsigned)line[p - 1 - i] : 0xFFu) << (8 * i);
+  reinterpret_cast<uint32_t *>(snap)[2] = packed;
+  reinterpret_cast<uint32_t *>(snap)[3] = 0;
+}
+
+template <class M>
+__global__ void __launch_bounds__(64)
+k_index_states(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
+               const uint32_t *__restrict__ tile_base, unsigned T, unsigned n_sym, unsigned stride,
+               const uint32_t *__restrict__ seg_prefix, const uint16_t *__restrict__ entry, int entry_is_xo,
+               unsigned S, const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
+               const uint16_t *__restrict__ final_state, uint8_t *__restrict__ index) {
+  extern __shared__ uint32_t lds[];
+  constexpr unsigned B = M::B;
+  const unsigned c = blockIdx.x;
+  const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
+  const unsigned n_snap = n_sym ? (n_sym - 1) / stride : 0u;
+  const unsigned k = blockIdx.y * 64 + fq_lane() + 1;
+  if (k > n_snap) return;
+  const unsigned size = 1u << t.log;
+  const unsigned n = arrays[c], run0 = arrays[B + c];
+  const unsigned rel = tile_base[(size_t)((k * stride) / T) * B + c] - run0;  // symbols of c in front of e
+  unsigned x = size;  // a context without symbols keeps its initial state
+  if (n) {
+    if (rel >= n) {
+      x = final_state[c];
+    } else {
+      const unsigned seg = rel / S;
+      const unsigned ev = entry[seg_prefix[c] + seg];
+      x = entry_is_xo ? size + (ev >> 1) : ev;
+      const uint8_t *sym = sorted_sym + run0;
+      for (unsigned i = seg * S; i < rel; i++) (void)chain_step(t, x, sym[i] & (unsigned)(M::A - 1));
+    }
+  }
+  uint16_t *st = reinterpret_cast<uint16_t *>(index + sizeof(FqIndexHeader) + (size_t)(k - 1) * (FQ_INDEX_SNAP_HEAD + 2 * (size_t)B) +
+                                              FQ_INDEX_SNAP_HEAD);
+  st[c] = (uint16_t)(x - size);
+}
+
 // Bit offsets of the packing tiles, size/overflow verdict and zeroing of the words shared by two
 // tiles, in ONE single-workgroup kernel: the per-tile counts are few (M / 4096) and every extra
 // launch on a block's critical path costs its scheduling latency on a busy GPU (measured ~0.8 ms
@@ -1677,7 +1747,7 @@ static unsigned fq_debug_skip() {
 
 template <class M>
 int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b,
-                  const uint32_t *rec_start, uint8_t *out_dev, size_t cap) {
+                  const uint32_t *rec_start, uint8_t *out_dev, size_t cap, unsigned flags) {
   EncScratch &sc = lane.enc[M::STREAM];
   const DevTables &tab = ctx->tab[M::STREAM];
   constexpr unsigned B = M::B;
@@ -1875,6 +1945,31 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if (!dbg_off) hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, final_state, tab.logs,
                      tab.log_prefix, reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
+  b->index_bytes[M::STREAM] = 0;
+  if ((flags & FQGPU_F_DECODE_INDEX) && !dbg_mask) {
+    const unsigned stride = ctx->index_stride;
+    const unsigned n_snap = n_sym ? (n_sym - 1) / stride : 0u;
+    const size_t bytes = sizeof(FqIndexHeader) + (size_t)n_snap * fq_index_snap_bytes(B);
+    if (bytes > b->index_cap[M::STREAM]) {
+      if (b->index[M::STREAM]) FQ_HIP(hipFree(b->index[M::STREAM]));
+      b->index[M::STREAM] = fq_dev_alloc<uint8_t>(bytes + 64);
+      b->index_cap[M::STREAM] = b->index[M::STREAM] ? bytes : 0;
+      if (!b->index[M::STREAM]) return FQGPU_E_NOMEM;
+    }
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.index" : "seq.index");
+    hipLaunchKernelGGL(k_index_meta<M>, dim3(n_snap / 256 + 1), dim3(256), 0, st, b->raw, b->recs, rec_start, R, n_sym,
+                       stride, sc.tile_bit_base.as<unsigned long long>(), b->index[M::STREAM]);
+    if (n_snap) {
+      const uint32_t *seg_prefix = serial_seq ? sc.seq_plan.as<uint32_t>() + 2 * (B + 1) : arrays + B + (B + 1);
+      const uint16_t *entry = serial_seq ? reinterpret_cast<const uint16_t *>(sc.seq_plan.as<uint32_t>() + SEGPLAN_WORDS)
+                                         : reinterpret_cast<const uint16_t *>(sc.seg_arrays.as<uint32_t>() + 3 * (size_t)gen_max_segs + 4);
+      hipLaunchKernelGGL(k_index_states<M>, dim3(B, (n_snap + 63) / 64), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                         arrays, sc.tile_base.as<uint32_t>(), T, n_sym, stride, seg_prefix, entry, serial_seq ? 1 : 0,
+                         serial_seq ? seq_S : S, tab.ct, tab.ct_off, final_state, b->index[M::STREAM]);
+    }
+    FQ_SPAN_END();
+    b->index_bytes[M::STREAM] = bytes;
+  }
   FQ_HIP(hipGetLastError());
   return FQGPU_OK;
 }
@@ -1966,8 +2061,8 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
   FQ_HIP(hipStreamWaitEvent(lane.st_qual, lane.ev_fork, 0));
   // timing experiments only (wrong output): one stream at a time
   static const bool dbg_no_qual = getenv("FQGPU_DEBUG_SKIP_QUAL") != nullptr, dbg_no_seq = getenv("FQGPU_DEBUG_SKIP_SEQ") != nullptr;
-  if (!dbg_no_qual && (rc = encode_stream<QualModel>(ctx, lane, lane.st_qual, b, rec_start, b->qual, b->qual_cap))) return rc;
-  if (!dbg_no_seq && (rc = encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, b->seq, b->seq_cap))) return rc;
+  if (!dbg_no_qual && (rc = encode_stream<QualModel>(ctx, lane, lane.st_qual, b, rec_start, b->qual, b->qual_cap, flags))) return rc;
+  if (!dbg_no_seq && (rc = encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, b->seq, b->seq_cap, flags))) return rc;
   FQ_HIP(hipEventRecord(lane.ev_join, lane.st_qual));
   FQ_HIP(hipStreamWaitEvent(lane.st_seq, lane.ev_join, 0));
 

@@ -135,12 +135,14 @@ struct fqgpu_ctx {
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
   unsigned seq_segment = 0;      // segment length of the sequence chain kernels (0 = default)
   bool lds_atomics_ordered = false;  // probed at creation: k_scatter may rank with LDS atomics
+  unsigned index_stride = 1u << 20;  // symbols between the snapshots of a decode index
   unsigned n_cus = 256;          // compute units of the device (grid of the persistent kernels)
   unsigned n_lanes = 4, next_lane = 0;
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch
   DevBuf n_cnt32, n_off, scan_tmp;
   DevBuf dec_desc;    // decode job descriptors
+  DevBuf dec_chunks, dec_recstart;  // chunk list and per-block rec_start of the indexed decode
   KernelTimer *timer = nullptr;
   // staging block of the host-pointer calls, kept between calls (grow-only device buffers)
   fqgpu_dblock *hp_block = nullptr;
@@ -164,7 +166,29 @@ struct fqgpu_dblock {
   BlockResult host_result;        // filled by fqgpu_sync-ing calls
   size_t seq_len = 0, qual_len = 0, n_pos_len = 0;  // stream sizes used by decode
   int last_op = 0;  // 1 = encode, 2 = decode: which fields of the result block are meaningful
+  // decode index (extension): device copy per stream, valid bytes, allocated bytes
+  uint8_t *index[2] = {nullptr, nullptr};
+  size_t index_bytes[2] = {0, 0}, index_cap[2] = {0, 0};
 };
+
+// Decode index of one stream: header, then one snapshot per multiple of `stride` symbols.
+struct FqIndexHeader {
+  uint32_t magic;    // 'FQIX'
+  uint32_t stream;   // 0 = sequence, 1 = quality
+  uint32_t stride;   // symbols between snapshots (multiple of 65536)
+  uint32_t n_snap;   // snapshots: encode indices stride, 2 stride, ... < n_sym
+  uint64_t n_sym;
+  uint64_t reserved;
+};
+// snapshot k (k = 1 .. n_snap) at encode index e = k * stride, FQ_INDEX_SNAP_HEAD + 2 B bytes:
+//   u64 bitpos     bits of the stream in front of symbol e
+//   u8  prev[4]    bytes at positions p-1 .. p-4 of the record of symbol e-1 (p = its position;
+//                  0xFF in front of the read): what the context model has seen when the decoder,
+//                  coming from the stream's end, is about to decode symbol e-1
+//   u32 reserved
+//   u16 state[B]   decoder state (encoder state - table size) of every context at that point
+constexpr unsigned FQ_INDEX_MAGIC = 0x58495146u, FQ_INDEX_SNAP_HEAD = 16;
+static inline size_t fq_index_snap_bytes(unsigned B) { return FQ_INDEX_SNAP_HEAD + 2 * (size_t)B; }
 
 // ---------------------------------------------------------------- launches (encode.hip / decode.hip / tables.hip)
 int fq_build_freq_tables(int device, hipStream_t st, const uint8_t *raw_dev, const fqgpu_rec *recs_dev,

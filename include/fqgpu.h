@@ -113,6 +113,13 @@ int fqgpu_ctx_dump_tables(fqgpu_ctx *ctx, int stream, unsigned model, uint32_t *
  * exceeding them returns FQGPU_E_OVERFLOW instead of the reference's silent 0.
  * flags: FQGPU_F_WRITE_BACK_N also rewrites N -> A inside `raw` like the reference. */
 #define FQGPU_F_WRITE_BACK_N 1u
+/* EXTENSION (not part of the reference format): the encode also leaves a
+ * decode index per stream -- every `stride` symbols the bit position of the stream, the decoder
+ * state of every context and the bytes the context model needs -- so that a decoder can start
+ * in the middle of a block.  With both indexes present fqgpu_dblocks_decode runs one lane per
+ * (block, stream, stride) instead of one per (block, stream); the streams themselves are the
+ * reference's, byte for byte, with or without the index. */
+#define FQGPU_F_DECODE_INDEX 2u
 int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
                        size_t n_recs, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
                        uint8_t *qual_out, size_t qual_cap, size_t *qual_len,
@@ -166,6 +173,13 @@ int fqgpu_dblock_longest_chain(const fqgpu_dblock *b, unsigned *seq_steps, unsig
 int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t *seq_out, uint8_t *qual_out,
                        uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
                        uint8_t *raw_out);
+/* decode index of one stream (0 = sequence, 1 = quality) of the last encode with
+ * FQGPU_F_DECODE_INDEX: size, copy to the host, and the way back for a later decode.  An index
+ * is only valid together with the streams it was made for (load it after the streams). */
+int fqgpu_ctx_set_index_stride(fqgpu_ctx *ctx, unsigned symbols); /* default 1 Mi, multiple of 64 Ki */
+int fqgpu_dblock_index_bytes(const fqgpu_dblock *b, int stream, size_t *bytes);
+int fqgpu_dblock_fetch_index(fqgpu_ctx *ctx, const fqgpu_dblock *b, int stream, void *out, size_t cap);
+int fqgpu_dblock_load_index(fqgpu_ctx *ctx, fqgpu_dblock *b, int stream, const void *data, size_t len);
 /* replaces the block's coded streams with host data (decode of foreign archives) */
 int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const uint8_t *seq, size_t seq_len,
                               const uint8_t *qual, size_t qual_len, const uint16_t *n_count,

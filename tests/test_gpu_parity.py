@@ -495,6 +495,55 @@ def test_full_size_roundtrip_1gib(F):
     assert total > (1 << 30) - 16 * 400
 
 
+# ---------------------------------------------------------------- extension: decode index
+@pytest.mark.parametrize("mode", [2, 4])
+def test_decode_index_parallel_decode(F, mode):
+    """FQGPU_F_DECODE_INDEX (extension): the streams stay the oracle's byte for
+    byte; with the index the block decodes with one lane per (stream, stride) -- mid-record starts,
+    N patching and mixed read lengths included -- and the index survives a trip through the host."""
+    raw, recs = _synth(F, mode, 14 << 20)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    ctx.set_index_stride(1 << 16)   # ~100 strides of 64 Ki symbols
+    b = ctx.dblock(raw, recs)
+    b.encode(flags=F.F_DECODE_INDEX)
+    ctx.sync()
+    g = b.fetch()
+    for k in ("seq", "qual", "n_count", "n_pos"):
+        assert np.array_equal(g[k], e[k]), k
+    ix = [b.fetch_index(0), b.fetch_index(1)]
+    n_sym = int(recs["len"].sum())
+    n_snap = (n_sym - 1) // (1 << 16)
+    assert ix[0].size == 32 + n_snap * (16 + 2 * 256) and ix[1].size == 32 + n_snap * (16 + 2 * 8192)
+    # bit positions grow, the last one lies inside the stream
+    bp = np.array([int(ix[1][32 + k * (16 + 2 * 8192):][:8].view(np.uint64)[0]) for k in range(n_snap)])
+    assert np.all(np.diff(bp) > 0) and bp[-1] < 8 * g["qual"].size
+    b.wipe()
+    ctx.decode_dblocks([b])
+    ctx.sync()
+    assert b.status()[0] == 0 and np.array_equal(b.fetch_raw(), raw)
+    b.close()
+    # a fresh block: streams and indexes come from the host
+    b2 = ctx.dblock(O.blank_skeleton(raw, recs), recs)
+    b2.load_streams(g["seq"], g["qual"], g["n_count"], g["n_pos"])
+    assert b2.load_index(0, ix[0]) == 0 and b2.load_index(1, ix[1]) == 0
+    ctx.decode_dblocks([b2])
+    ctx.sync()
+    assert b2.status()[0] == 0 and np.array_equal(b2.fetch_raw(), raw)
+    # a damaged index is refused, a missing one just means the one-lane-per-stream decoder
+    bad = ix[1].copy(); bad[0] ^= 1
+    assert b2.load_index(1, bad) != 0
+    assert b2.load_index(1, ix[1][:-2]) != 0
+    assert b2.load_index(1, np.zeros(0, dtype=np.uint8)) == 0
+    b2.wipe()
+    ctx.decode_dblocks([b2])
+    ctx.sync()
+    assert b2.status()[0] == 0 and np.array_equal(b2.fetch_raw(), raw)
+    b2.close()
+    ctx.close()
+
+
 # ---------------------------------------------------------------- the C++ drop-in shim
 def test_cpp_workspace_shim_roundtrip(golden_dir):
     """fqcomp28_amd/csrc/workspace.hpp (the reference's Workspace/CompressedBuffers surface over the
