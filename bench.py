@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--segment", type=int, default=0, help="segment length of the generic (quality) chain kernels")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank); gloo only to rehearse the "
                     "multi-rank path on a one-GPU box (all ranks then share GPU 0)")
+    ap.add_argument("--index-stride", type=int, default=1 << 20, help="symbols between the snapshots of the decode index")
     ap.add_argument("--skip-decode", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     args = ap.parse_args()
@@ -249,6 +250,34 @@ def main():
         extra["decode_MBps"] = round(total_raw / dt / MB, 1)
         extra["decode_blocks_per_gpu"] = len(dblocks)
         extra["decode_roundtrip_ok"] = ok
+        # extension: the same blocks coded with a decode index (identical streams + a sidecar of
+        # snapshots every --index-stride symbols), decoded with one lane per (stream, stride)
+        ctx.set_index_stride(args.index_stride)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for b in dblocks:
+            b.encode(flags=F.F_DECODE_INDEX)
+        ctx.sync()
+        t_enc_ix = time.perf_counter() - t0
+        ix_bytes = sum(b.fetch_index(0).size + b.fetch_index(1).size for b in dblocks)
+        same = all(b.status()[1]["seq_len"] == s["seq_len"] and b.status()[1]["qual_len"] == s["qual_len"]
+                   for b, s in zip(dblocks, sizes))
+        for b in dblocks:
+            b.wipe()
+        ctx.sync()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.decode_dblocks(dblocks)
+        ctx.sync()
+        barrier()
+        dt_ix = reduce_max(time.perf_counter() - t0, dist)
+        ok_ix = all(b.status()[0] == 0 for b in dblocks) and \
+            bool(np.array_equal(dblocks[-1].fetch_raw(), blocks[-1][0]))
+        extra["decode_with_index"] = {"MBps": round(total_raw / dt_ix / MB, 1), "stride_symbols": args.index_stride,
+                                      "index_bytes_per_gpu": int(ix_bytes),
+                                      "index_over_streams": round(ix_bytes / max(1, seq_bytes + qual_bytes), 5),
+                                      "encode_with_index_ms": round(t_enc_ix * 1e3, 2), "streams_unchanged": bool(same),
+                                      "roundtrip_ok": ok_ix}
         for b in dblocks:
             b.close()
         dblocks = []

@@ -42,6 +42,19 @@ typedef FQ_GLOBAL uint8_t g_u8;
 typedef const FQ_GLOBAL uint32_t g_cu32;
 typedef const FQ_GLOBAL fqgpu_rec g_crec;
 
+// Per context ONE LDS word: decoder state (12 bits, log <= 12) | the context's DTable position.
+// DTables lie back to back, 1 + 2^log words each (log >= 5), so dt_off[c] - c is a multiple of 32
+// and (dt_off[c] - c) / 32 < 2^20: word = that << 12 | state; entry = dt[(word >> 12) * 32 + c + 1 + state].
+// 32 KB of LDS per quality lane instead of 48 KB (16-bit states + 32-bit offsets): five lanes per CU
+// for the strides of the indexed decode, where the number of resident lanes is what counts (the
+// one-lane-per-stream kernel keeps the two arrays: one ALU op less on its dependent chain).
+__device__ __forceinline__ uint32_t fq_pack_state(uint32_t dt_off_c, unsigned c, unsigned state) {
+  return (((dt_off_c - c) >> 5) << 12) | (state & 0xFFFu);
+}
+__device__ __forceinline__ uint32_t fq_entry_index(uint32_t word, unsigned c) {
+  return ((word >> 12) << 5) + c + 1u + (word & 0xFFFu);
+}
+
 struct TabView {
   const uint32_t *logs, *log_prefix, *dt, *dt_off;
 };
@@ -148,7 +161,7 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *sta
 // stream for the last stride): encode indices [e_lo, e_hi) in decoder order, i.e. from the record
 // and position of symbol e_hi - 1 towards the front of the block.
 template <class M>
-__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, uint16_t *state, uint32_t *dt_off) {
+__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, uint32_t *pk) {
   constexpr unsigned B = M::B;
   const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
@@ -175,8 +188,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     if (p0 < (long long)sum_logs) { if (lane == 0) res->corrupt = 1; return; }
     for (unsigned c = lane; c < B; c += 64) {
       const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
-      state[c] = (uint16_t)peek_bits(w, lo, tab.logs[c]);
-      dt_off[c] = tab.dt_off[c] + 1u;
+      pk[c] = fq_pack_state(tab.dt_off[c], c, peek_bits(w, lo, tab.logs[c]));
     }
     pos = p0 - (long long)sum_logs;
     if (lane == 0) res->total_bits = (unsigned long long)pos;
@@ -184,8 +196,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     const uint8_t *snap = snaps + (size_t)chunk * snap_bytes;  // snapshot chunk + 1 sits at e_hi
     const uint16_t *st = reinterpret_cast<const uint16_t *>(snap + FQ_INDEX_SNAP_HEAD);
     for (unsigned c = lane; c < B; c += 64) {
-      state[c] = st[c];
-      dt_off[c] = tab.dt_off[c] + 1u;
+      pk[c] = fq_pack_state(tab.dt_off[c], c, st[c]);
     }
     pos = (long long)*reinterpret_cast<const unsigned long long *>(snap);
     prev = reinterpret_cast<const uint32_t *>(snap)[2];
@@ -220,9 +231,10 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
           if (ch != 0xFFu) ctx = (ctx >> 2) + (fq_base_code(ch) << 6);
         }
       for (unsigned i = i0; i < i1; i++) {
-        const uint32_t e = dt[dt_off[ctx] + state[ctx]];
+        const uint32_t v = pk[ctx];
+        const uint32_t e = dt[fq_entry_index(v, ctx)];
         const unsigned sym = (e >> 16) & 3u;
-        state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
+        pk[ctx] = (v & ~0xFFFu) | ((e & 0xFFFFu) + br.read(e >> 24));
         out[i] = (uint8_t)(0x54474341u >> (8u * sym));
         ctx = (ctx >> 2) + (sym << 6);
       }
@@ -237,9 +249,10 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
         q1 = qa; q2 = qb;
       }
       for (unsigned i = i0; i < i1; i++) {
-        const uint32_t e = dt[dt_off[ctx] + state[ctx]];
+        const uint32_t v = pk[ctx];
+        const uint32_t e = dt[fq_entry_index(v, ctx)];
         const unsigned q = (e >> 16) & 63u;
-        state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
+        pk[ctx] = (v & ~0xFFFu) | ((e & 0xFFFFu) + br.read(e >> 24));
         out[i] = (uint8_t)(q + 33u);
         ctx = fq_qual_ctx(q, q1, q2);
         q2 = q1;
@@ -255,11 +268,10 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
 
 __global__ void __launch_bounds__(64)
 k_decode_chunks(const DecJob *__restrict__ jobs, const DecChunk *__restrict__ chunks, TabView seq_tab, TabView qual_tab) {
-  __shared__ uint16_t state[QualModel::B];
-  __shared__ uint32_t dt_off[QualModel::B];
+  __shared__ uint32_t pk[QualModel::B];
   const DecChunk ch = chunks[blockIdx.x];
-  if (ch.stream) decode_chunk<QualModel>(jobs[ch.job], ch.chunk, qual_tab, state, dt_off);
-  else decode_chunk<SeqModel>(jobs[ch.job], ch.chunk, seq_tab, state, dt_off);
+  if (ch.stream) decode_chunk<QualModel>(jobs[ch.job], ch.chunk, qual_tab, pk);
+  else decode_chunk<SeqModel>(jobs[ch.job], ch.chunk, seq_tab, pk);
 }
 
 // record lengths of one block, for the encode index of the first symbol of every record
