@@ -1,0 +1,292 @@
+// Part of encode.hip (included there, inside its anonymous namespace): record-level kernels, the encode-order symbol walker, K1 (tile histograms + keys), K2 (layout).
+
+// ------------------------------------------------------------------ record-level kernels
+
+// readlens + N count per record (replaceAndEncodeNs, src/fse_sequence.cpp:35-51, first half).
+// One wave per record, lanes stride the bases.
+__global__ void __launch_bounds__(256)
+k_readlens_ncount(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R,
+                  uint16_t *__restrict__ readlens, uint16_t *__restrict__ n_count,
+                  uint32_t *__restrict__ n_cnt32, uint32_t *__restrict__ lens32) {
+  const unsigned waves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned lane = fq_lane();
+  for (unsigned r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < R; r += waves) {
+    const fqgpu_rec rec = recs[r];
+    const uint8_t *s = raw + rec.seq_off;
+    unsigned cnt = 0;
+    for (unsigned base = 0; base < rec.len; base += 64) {
+      const unsigned i = base + lane;
+      const bool isn = i < rec.len && s[i] == 'N';
+      cnt += (unsigned)__popcll(__ballot(isn));
+    }
+    if (lane == 0) {
+      readlens[r] = (uint16_t)rec.len;
+      n_count[r] = (uint16_t)cnt;
+      n_cnt32[r] = cnt;
+      lens32[r] = rec.len;
+    }
+  }
+}
+
+// N position deltas (second half of replaceAndEncodeNs) + optional N -> A write-back
+__global__ void __launch_bounds__(256)
+k_npos(uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R,
+       const uint32_t *__restrict__ n_off, uint16_t *__restrict__ n_pos, int write_back) {
+  const unsigned waves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned lane = fq_lane();
+  for (unsigned r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < R; r += waves) {
+    const unsigned first = n_off[r];
+    if (n_off[r + 1] == first) continue;  // no N in this record
+    const fqgpu_rec rec = recs[r];
+    uint8_t *s = raw + rec.seq_off;
+    unsigned done = 0, prev = 0;  // N's written so far, position of the last one (0 before any)
+    for (unsigned base = 0; base < rec.len; base += 64) {
+      const unsigned i = base + lane;
+      const bool isn = i < rec.len && s[i] == 'N';
+      const unsigned long long m = __ballot(isn);
+      if (isn) {
+        const unsigned long long below = m & ((1ull << lane) - 1ull);
+        const unsigned p = below ? base + (63u - (unsigned)__clzll(below)) : prev;
+        n_pos[first + done + (unsigned)__popcll(below)] = (uint16_t)(i - p);
+        if (write_back) s[i] = 'A';
+      }
+      if (m) prev = base + (63u - (unsigned)__clzll(m));
+      done += (unsigned)__popcll(m);
+    }
+  }
+}
+
+__global__ void k_store_npos_len(const uint32_t *__restrict__ n_off, unsigned R, BlockResult *res) {
+  res->n_pos_len = n_off[R];
+}
+
+// ------------------------------------------------------------------ walking symbols in encode order
+// Encode order = records in file order, positions L-1 .. 0 inside a record
+// (src/fse_sequence.cpp:76-77,101; src/fse_quality.cpp:7,19).  A wave walks a range of encode
+// indices 64 at a time; the record of every lane is found by stepping through the (few)
+// records a chunk touches with wave-uniform loads instead of a per-lane binary search.
+// The records a wave is walking through are cached 64 at a time in LDS (one coalesced load per
+// 64 records instead of a dependent global round trip in front of every 64-symbol chunk).
+struct RecCache {
+  uint32_t start[65];   // rec_start of records r0 .. r0 + 64
+  fqgpu_rec rec[64];
+};
+
+constexpr int K1_DEPTH = 4;  // chunk buffers of K1's software pipeline
+
+struct SymbolWalker {
+  const fqgpu_rec *__restrict__ recs;
+  const uint32_t *__restrict__ rec_start;
+  unsigned r;   // record holding the first symbol of the next chunk (wave-uniform)
+  unsigned R;   // number of records
+  RecCache *cache;
+  unsigned r0;  // first cached record
+
+  // window of 64 records starting at `first`; returns the first encode index it does NOT cover
+  __device__ __forceinline__ unsigned refill(unsigned first) {
+    const unsigned lane = fq_lane();
+    r0 = first;
+    fq_lds_wave_sync();  // nobody still reads the old window
+    cache->start[lane] = first + lane <= R ? rec_start[first + lane] : 0xFFFFFFFFu;
+    if (lane == 0) cache->start[64] = first + 64 <= R ? rec_start[first + 64] : 0xFFFFFFFFu;
+    if (first + lane < R) cache->rec[lane] = recs[first + lane];
+    fq_lds_wave_sync();
+    return __builtin_amdgcn_readfirstlane(cache->start[64]);
+  }
+
+  // lanes with valid == true get their record and position.  The chunk [eb, eb + 64) must lie
+  // inside the cached window (no global memory operation in here).
+  __device__ __forceinline__ void locate(unsigned eb, unsigned e_end, unsigned e, bool valid,
+                                         fqgpu_rec &rec, unsigned &p) {
+    const unsigned chunk_end = min(eb + 64u, e_end);
+    unsigned rr = r;
+    rec.seq_off = rec.qual_off = rec.len = 0;
+    p = 0;
+    for (;;) {
+      const unsigned k = rr - r0;
+      const unsigned rs = __builtin_amdgcn_readfirstlane(cache->start[k]),
+                     rn = __builtin_amdgcn_readfirstlane(cache->start[k + 1]);
+      if (valid && e >= rs && e < rn) { rec = cache->rec[k]; p = rec.len - 1u - (e - rs); }
+      if (rn > chunk_end) break;            // record rr continues into the next chunk
+      rr++;
+      if (rn == chunk_end) break;           // next chunk starts exactly at record rr
+    }
+    r = rr;
+  }
+};
+
+// ------------------------------------------------------------------ K1: per-tile context histogram
+// Also leaves the key of every symbol in encode order, so that the partition pass is a plain
+// prefetchable linear scan: ckey[e] = ctx | sym << 8 (sequence: 10 bits) or ctx (quality: 13
+// bits, the symbol goes to csym[e]).  Two or three bytes per symbol instead of four: the key
+// stores alone were 2.7 of the 21 ms step (tools/traffic_experiment.py).
+template <class M>
+__global__ void __launch_bounds__(256)
+k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
+            const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
+            uint32_t *__restrict__ tile_hist, uint16_t *__restrict__ ckey, uint8_t *__restrict__ csym,
+            StreamResult *res, int dbg) {
+  __shared__ uint32_t hist[M::B];
+  __shared__ RecCache rcache[4];  // one per wave
+  const unsigned tile = blockIdx.x;
+  const unsigned e0 = tile * T;
+  const unsigned e1 = min(e0 + T, n_sym);
+  for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x) hist[c] = 0;
+  __syncthreads();
+  // every wave takes a contiguous share of the tile (multiple of 64 symbols)
+  const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
+  const unsigned per = (((e1 - e0) + blockDim.x - 1u) / blockDim.x) * 64u;
+  const unsigned wb = min(e0 + wave * per, e1), we = min(wb + per, e1);
+  bool bad = false;
+  if (wb < we) {
+    SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb), R, &rcache[wave], 0};
+    // Software pipeline over a ring of K1_DEPTH chunk buffers: the bytes of chunk i + K1_DEPTH - 1
+    // are requested before chunk i is hashed, so a load has K1_DEPTH - 1 chunks of work to land.
+    // (A two-stage version with "cur = nxt" at the end of the iteration made the register copy
+    // wait for the load it had just issued: the full global latency in every iteration.)  The
+    // pipeline runs over the chunks that lie inside one 64-record window of the LDS cache, so that
+    // its body contains no global memory operation besides the byte loads and the key stores and
+    // the compiler can keep several chunks' loads outstanding.
+    SymBytes buf[K1_DEPTH];
+    unsigned bp[K1_DEPTH];
+    unsigned lim = 0;  // end (encode index) of the chunks of the current window
+    auto fetch = [&](int slot, unsigned eb2) {
+      const unsigned e2 = eb2 + lane;
+      const bool v2 = e2 < lim;
+      fqgpu_rec rec;
+      unsigned p;
+      w.locate(eb2, lim, e2, v2, rec, p);
+      buf[slot] = fq_load_sym_bytes<M>(raw, rec, p, v2);
+      bp[slot] = p;
+    };
+    auto consume = [&](int slot, unsigned eb2) {
+      const unsigned e = eb2 + lane;
+      if (e < lim) {
+        unsigned ctx, sym;
+        fq_ctx_from_bytes<M>(buf[slot], bp[slot], ctx, sym);
+        bad |= sym >= (unsigned)M::A;
+        if (!(dbg & 2)) {
+          if (M::STREAM == 0) ckey[e] = (uint16_t)(ctx | ((sym & 3u) << 8));
+          else { ckey[e] = (uint16_t)ctx; csym[e] = (uint8_t)(sym & 63u); }
+        }
+        if (!(dbg & 1)) atomicAdd(&hist[ctx], 1u);
+      }
+    };
+    for (unsigned eb = wb; eb < we;) {
+      const unsigned covered = w.refill(w.r);  // records w.r .. w.r + 63
+      // whole chunks inside the window (the wave's last chunk may be short)
+      lim = covered >= we ? we : wb + ((covered - wb) & ~63u);
+#pragma unroll
+      for (int d = 0; d < K1_DEPTH - 1; d++)
+        if (eb + 64u * d < lim) fetch(d, eb + 64u * d);
+      // steady state: straight-line fetch / consume (no branch the load counters could get lost in)
+      for (; eb + 64u * (2 * K1_DEPTH - 2) < lim; eb += 64u * K1_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < K1_DEPTH; d++) {
+          fetch((d + K1_DEPTH - 1) % K1_DEPTH, eb + 64u * (d + K1_DEPTH - 1));
+          consume(d, eb + 64u * d);
+        }
+      }
+      for (; eb < lim; eb += 64u * K1_DEPTH) {  // drain
+#pragma unroll
+        for (int d = 0; d < K1_DEPTH; d++) {
+          const unsigned cur = eb + 64u * d;
+          if (cur < lim) {
+            const unsigned nxt = cur + 64u * (K1_DEPTH - 1);
+            if (nxt < lim) fetch((d + K1_DEPTH - 1) % K1_DEPTH, nxt);
+            consume(d, cur);
+          }
+        }
+      }
+      eb = lim;
+    }
+  }
+  if (bad) atomicOr(&res->bad_symbol, 1u);
+  __syncthreads();
+  if (dbg & 1) return;  // timing experiment: the previous encode's histogram stays
+  for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x)
+    tile_hist[(size_t)tile * M::B + c] = hist[c];
+}
+
+// ------------------------------------------------------------------ K2: layout of the sorted arrays
+// group_sum[g][c] = sum of tile_hist over the tiles of group g
+__global__ void __launch_bounds__(256)
+k_group_sum(const uint32_t *__restrict__ tile_hist, unsigned n_tiles, unsigned B,
+            uint32_t *__restrict__ group_sum) {
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned g = blockIdx.y;
+  if (c >= B) return;
+  const unsigned t0 = g * GROUP_TILES, t1 = min(t0 + GROUP_TILES, n_tiles);
+  uint32_t acc = 0;
+  for (unsigned t = t0; t < t1; t++) acc += tile_hist[(size_t)t * B + c];
+  group_sum[(size_t)g * B + c] = acc;
+}
+
+// One workgroup: per-context totals, exclusive scan over groups (in place), then the
+// context layout: padded start of every context's run, segment and work-item prefix sums.
+// arrays: ctx_count[B] | ctx_start[B+1] | seg_base[B+1] | item_base[B+1]
+__global__ void __launch_bounds__(1024)
+k_ctx_layout(uint32_t *__restrict__ group_sum, unsigned n_groups, unsigned B, unsigned S,
+             uint32_t *__restrict__ arrays) {
+  __shared__ unsigned part[3][1024];
+  uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
+           *item_base = seg_base + B + 1;
+  for (unsigned c = threadIdx.x; c < B; c += blockDim.x) {
+    uint32_t acc = 0;
+    for (unsigned g = 0; g < n_groups; g++) {
+      const uint32_t v = group_sum[(size_t)g * B + c];
+      group_sum[(size_t)g * B + c] = acc;
+      acc += v;
+    }
+    ctx_count[c] = acc;
+  }
+  __syncthreads();
+  // blocked scan: thread t owns contexts [t*per, (t+1)*per)
+  const unsigned per = (B + blockDim.x - 1) / blockDim.x;
+  const unsigned c0 = threadIdx.x * per, c1 = min(c0 + per, B);
+  unsigned a0 = 0, a1 = 0, a2 = 0;
+  for (unsigned c = c0; c < c1; c++) {
+    const unsigned n = ctx_count[c];
+    const unsigned nseg = (n + S - 1) / S;
+    a0 += (n + CTX_PAD - 1) & ~(CTX_PAD - 1);
+    a1 += nseg;
+    a2 += (nseg + 63) >> 6;
+  }
+  part[0][threadIdx.x] = a0; part[1][threadIdx.x] = a1; part[2][threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x < 3) {  // three short serial scans over 1024 partials
+    unsigned run = 0;
+    for (unsigned i = 0; i < blockDim.x; i++) {
+      const unsigned v = part[threadIdx.x][i];
+      part[threadIdx.x][i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  a0 = part[0][threadIdx.x]; a1 = part[1][threadIdx.x]; a2 = part[2][threadIdx.x];
+  for (unsigned c = c0; c < c1; c++) {
+    const unsigned n = ctx_count[c];
+    const unsigned nseg = (n + S - 1) / S;
+    ctx_start[c] = a0; seg_base[c] = a1; item_base[c] = a2;
+    a0 += (n + CTX_PAD - 1) & ~(CTX_PAD - 1);
+    a1 += nseg;
+    a2 += (nseg + 63) >> 6;
+  }
+  if (c1 == B && c0 < B) { ctx_start[B] = a0; seg_base[B] = a1; item_base[B] = a2; }
+}
+
+// tile_base[t][c] = ctx_start[c] + (symbols of context c in tiles before t)
+__global__ void __launch_bounds__(256)
+k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ group_sum,
+            const uint32_t *__restrict__ ctx_start, unsigned n_tiles, unsigned B,
+            uint32_t *__restrict__ tile_base) {
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned g = blockIdx.y;
+  if (c >= B) return;
+  const unsigned t0 = g * GROUP_TILES, t1 = min(t0 + GROUP_TILES, n_tiles);
+  uint32_t acc = ctx_start[c] + group_sum[(size_t)g * B + c];
+  for (unsigned t = t0; t < t1; t++) {
+    tile_base[(size_t)t * B + c] = acc;
+    acc += tile_hist[(size_t)t * B + c];
+  }
+}
