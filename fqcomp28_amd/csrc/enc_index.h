@@ -46,15 +46,21 @@ k_index_states(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restric
   extern __shared__ uint32_t lds[];
   constexpr unsigned B = M::B;
   const unsigned c = blockIdx.x;
-  const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
   const unsigned n_snap = n_sym ? (n_sym - 1) / stride : 0u;
   const unsigned k = blockIdx.y * 64 + fq_lane() + 1;
+  const unsigned n = arrays[c], run0 = arrays[B + c];
+  if (n == 0) {  // (uniform) a context without symbols keeps its initial state: decoder state 0
+    if (k <= n_snap)
+      reinterpret_cast<uint16_t *>(index + sizeof(FqIndexHeader) + (size_t)(k - 1) * (FQ_INDEX_SNAP_HEAD + 2 * (size_t)B) +
+                                   FQ_INDEX_SNAP_HEAD)[c] = 0;
+    return;
+  }
+  const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
   if (k > n_snap) return;
   const unsigned size = 1u << t.log;
-  const unsigned n = arrays[c], run0 = arrays[B + c];
   const unsigned rel = tile_base[(size_t)((k * stride) / T) * B + c] - run0;  // symbols of c in front of e
-  unsigned x = size;  // a context without symbols keeps its initial state
-  if (n) {
+  unsigned x;
+  {
     if (rel >= n) {
       x = final_state[c];
     } else {
