@@ -195,6 +195,56 @@ def test_extreme_read_lengths(F, case):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_blocks_match_oracle(F, seed):
+    """Randomised blocks: read lengths from 3 to a few thousand, quality alphabets from one value to
+    all 64 (chars 33..96), bases with N runs, tables from the block itself or from another block
+    (symbols the tables have never seen); encode must equal the oracle and decode must restore."""
+    rng = np.random.default_rng(1000 + seed)
+    n_reads = int(rng.integers(1, 4000))
+    kind = seed % 4
+    if kind == 0:
+        lengths = rng.integers(3, 12, size=n_reads)
+    elif kind == 1:
+        lengths = rng.integers(3, 400, size=n_reads)
+    elif kind == 2:
+        lengths = np.where(rng.random(n_reads) < 0.02, rng.integers(2000, 9000, size=n_reads), rng.integers(30, 160, size=n_reads))
+    else:
+        lengths = np.full(n_reads, int(rng.integers(3, 300)))
+    qlo = int(rng.integers(0, 60)); qhi = int(rng.integers(qlo, 64))
+
+    def make(lengths, salt):
+        r2 = np.random.default_rng(5000 + 17 * seed + salt)
+        parts = []
+        for i, L in enumerate(lengths):
+            L = int(L)
+            seq = np.frombuffer(b"ACGT", dtype=np.uint8)[r2.integers(0, 4, size=L)].copy()
+            if r2.random() < 0.3:
+                a = int(r2.integers(0, L)); seq[a: a + int(r2.integers(1, 8))] = ord("N")
+            q = (r2.integers(qlo, qhi + 1, size=L) + 33).astype(np.uint8)
+            parts.append(b"@x%d\n" % i + seq.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+        raw = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+        return raw, O.parse_fastq(raw)
+
+    raw, recs = make(lengths, 0)
+    if seed % 3 == 0:   # tables from a different sample
+        traw, trecs = make(lengths[: max(1, n_reads // 3)], 1)
+    else:
+        traw, trecs = raw, recs
+    _, _, sft, qft = O.freq_tables(traw, trecs)
+    gs, gq = F.freq_tables(traw, trecs)
+    assert gs.tobytes() == sft.tobytes() and gq.tobytes() == qft.tobytes()
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    g = ctx.encode_block(raw, recs, flags=1)
+    assert g["rc"] == e["rc"]
+    if e["rc"] == 0:
+        assert_same_encoding(g, e)
+        rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, O.blank_skeleton(raw, recs))
+        assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
 def test_partition_fallback_without_lane_ordered_lds_atomics(F, golden_dir, monkeypatch):
     """The partition kernels rank with lane-ordered LDS atomics when the handle's probe confirms the
     ordering; FQGPU_NO_LDS_ATOMIC_RANK forces the ballot-match kernels a device without that
