@@ -196,7 +196,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     const uint8_t *snap = snaps + (size_t)chunk * snap_bytes;  // snapshot chunk + 1 sits at e_hi
     const uint16_t *st = reinterpret_cast<const uint16_t *>(snap + FQ_INDEX_SNAP_HEAD);
     for (unsigned c = lane; c < B; c += 64) {
-      pk[c] = fq_pack_state(tab.dt_off[c], c, st[c]);
+      pk[c] = fq_pack_state(tab.dt_off[c], c, (unsigned)st[c] & ((1u << tab.logs[c]) - 1u));  // a damaged index must not leave the table
     }
     pos = (long long)*reinterpret_cast<const unsigned long long *>(snap);
     prev = reinterpret_cast<const uint32_t *>(snap)[2];
