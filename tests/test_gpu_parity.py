@@ -245,6 +245,52 @@ def test_random_blocks_match_oracle(F, seed):
     ctx.close()
 
 
+def _rescale_tables(ft, new_log):
+    """FreqTable POD with every context renormalised to 2^new_log (largest-remainder on the old
+    normalised counts, -1 entries kept): tables a foreign writer could have produced."""
+    out = ft.copy()
+    norm = out["norm"][0]
+    logs = out["logs"][0]
+    for c in range(norm.shape[0]):
+        old = norm[c].astype(np.int64)
+        cnt = np.where(old == -1, 1, old)
+        tot = int(cnt.sum())
+        target = 1 << new_log
+        scaled = np.where(cnt > 0, np.maximum(1, cnt * target // tot), 0)
+        scaled[np.argmax(scaled)] += target - int(scaled.sum())
+        assert scaled.min() >= 0 and int(scaled.sum()) == target and scaled[np.argmax(scaled)] > 0
+        norm[c] = np.where((old == -1) & (scaled == 1), -1, scaled).astype(norm.dtype)
+        logs[c] = new_log
+    out["max_log"][0] = new_log
+    return out
+
+
+@pytest.mark.parametrize("log", [12, 5])
+def test_foreign_table_logs(F, log):
+    """Tables with log 12 everywhere (the reference never builds them: FSE_DEFAULT_TABLELOG = 11, but
+    the format allows them) and with log 5 where the alphabet fits: 64 states per lane in the
+    segment-function kernels, one-symbol table for the sequence stream, 8.7 KB CTables."""
+    raw, recs = _synth(F, 2, 5 << 20)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    sft2 = _rescale_tables(sft, log)
+    qft2 = _rescale_tables(qft, 12) if log == 12 else qft  # (64 symbols do not fit a tiny table)
+    octx = O.OracleCtx(sft2, qft2)
+    ctx = F.Context(sft2, qft2)
+    e = octx.encode(raw, recs)
+    g = ctx.encode_block(raw, recs)
+    if log == 5:
+        # 5-bit probabilities of uniform bases cost more than 2 bits per base: the sequence stream
+        # does not fit the reference's capacity rule and both coders say so
+        assert e["rc"] == -1 and g["rc"] == -1
+        cap = int(recs["len"].sum())  # generous capacities: same bytes again
+        e = octx.encode(raw, recs, seq_cap=cap, qual_cap=cap)
+        g = ctx.encode_block(raw, recs, seq_cap=cap, qual_cap=cap)
+    assert_same_encoding(g, e)
+    rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
 def test_partition_fallback_without_lane_ordered_lds_atomics(F, golden_dir, monkeypatch):
     """The partition kernels rank with lane-ordered LDS atomics when the handle's probe confirms the
     ordering; FQGPU_NO_LDS_ATOMIC_RANK forces the ballot-match kernels a device without that
