@@ -592,15 +592,17 @@ def test_full_size_roundtrip_1gib(F):
 
 
 # ---------------------------------------------------------------- extension: decode index
-@pytest.mark.parametrize("mode", [2, 4])
+@pytest.mark.parametrize("mode", [2, 4, -2])
 def test_decode_index_parallel_decode(F, mode):
     """FQGPU_F_DECODE_INDEX (extension): the streams stay the oracle's byte for
     byte; with the index the block decodes with one lane per (stream, stride) -- mid-record starts,
     N patching and mixed read lengths included -- and the index survives a trip through the host."""
-    raw, recs = _synth(F, mode, 14 << 20)
+    raw, recs = _synth(F, abs(mode), 14 << 20)
     _, _, sft, qft = O.freq_tables(raw, recs)
     e = O.OracleCtx(sft, qft).encode(raw, recs)
     ctx = F.Context(sft, qft)
+    if mode < 0:  # the sequence stream through the generic (reset-aware) chain kernels
+        ctx.set_chain_params(1024, seq_generic=True)
     ctx.set_index_stride(1 << 16)   # ~100 strides of 64 Ki symbols
     b = ctx.dblock(raw, recs)
     b.encode(flags=F.F_DECODE_INDEX)
