@@ -195,7 +195,7 @@ def test_extreme_read_lengths(F, case):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FQ_FUZZ_SEEDS", "12"))))
 def test_random_blocks_match_oracle(F, seed):
     """Randomised blocks: read lengths from 3 to a few thousand, quality alphabets from one value to
     all 64 (chars 33..96), bases with N runs, tables from the block itself or from another block
