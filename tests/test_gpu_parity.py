@@ -291,6 +291,37 @@ def test_foreign_table_logs(F, log):
     ctx.close()
 
 
+def test_one_handle_per_thread(F):
+    """The reference runs one workspace per worker thread (src/process.cpp:49-54): three host threads,
+    each with its own handle on the same GPU, code different blocks at the same time."""
+    import threading
+    jobs = []
+    for i, mode in enumerate((2, 4, 2)):
+        raw, recs = _synth(F, mode, (3 + i) << 20, seed=40 + i)
+        _, _, sft, qft = O.freq_tables(raw, recs)
+        jobs.append((raw, recs, sft, qft, O.OracleCtx(sft, qft).encode(raw, recs)))
+    errors = []
+
+    def worker(raw, recs, sft, qft, e):
+        try:
+            ctx = F.Context(sft, qft)
+            for _ in range(3):
+                g = ctx.encode_block(raw, recs)
+                assert_same_encoding(g, e)
+                rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, O.blank_skeleton(raw, recs))
+                assert rc == 0 and np.array_equal(out, raw)
+            ctx.close()
+        except BaseException as ex:  # noqa: BLE001 - reported by the main thread
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_partition_fallback_without_lane_ordered_lds_atomics(F, golden_dir, monkeypatch):
     """The partition kernels rank with lane-ordered LDS atomics when the handle's probe confirms the
     ordering; FQGPU_NO_LDS_ATOMIC_RANK forces the ballot-match kernels a device without that
