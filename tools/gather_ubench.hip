@@ -1,6 +1,10 @@
 // Micro-benchmark: throughput of 64-lane random u16 LDS gathers (the inner operation of a
 // candidate-set walk): WAVES waves per workgroup share one 16 KB next[s][x] table, every lane
 // advances M independent states per symbol.  Reports wave-gathers per cycle per CU.
+// Two tables: "random" (a random function: the lanes' states coalesce within a few steps, most
+// lanes then read the same few dwords and the LDS broadcasts) and "permutation" (every row a
+// bijection: 64 lanes keep 64 DISTINCT states, the situation of the state-set walk, where the
+// classes a wave carries are distinct by construction).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/gather_ubench.hip -o tools/_build/gather_ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,11 +39,20 @@ __global__ void __launch_bounds__(1024) k(const uint16_t *tab, const uint32_t *s
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-int main() {
+int main(int argc, char **argv) {
   const unsigned n_words = 2048;  // 32768 symbols per wave
+  const bool perm = argc > 1 && argv[1][0] == 'p';
   std::vector<uint16_t> tab(4 * SIZE);
   srand(1);
   for (auto &v : tab) v = (uint16_t)((rand() % SIZE) * 2);
+  if (perm)
+    for (unsigned r = 0; r < 4; r++) {
+      std::vector<uint16_t> p(SIZE);
+      for (unsigned i = 0; i < SIZE; i++) p[i] = (uint16_t)(i * 2);
+      for (unsigned i = SIZE - 1; i > 0; i--) std::swap(p[i], p[rand() % (i + 1)]);
+      for (unsigned i = 0; i < SIZE; i++) tab[r * SIZE + i] = p[i];
+    }
+  printf("table: %s\n", perm ? "permutation rows (lanes keep distinct states)" : "random function (states coalesce)");
   const unsigned max_waves = 256 * 32 * 2;
   std::vector<uint32_t> sym((size_t)max_waves * n_words);
   for (auto &v : sym) v = (uint32_t)rand() * 2654435761u;
