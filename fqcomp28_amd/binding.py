@@ -92,6 +92,7 @@ _PROTOS = {
     "fqgpu_dblock_load_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "fqgpu_ctx_set_lanes": (C.c_int, [C.c_void_p, C.c_uint]),
     "fqgpu_ctx_set_seq_segment": (C.c_int, [C.c_void_p, C.c_uint]),
+    "fqgpu_ctx_set_seq_group": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint]),
     "fqgpu_dblock_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "fqgpu_dblock_load_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -290,10 +291,14 @@ class Context:
 
     __del__ = close
 
-    def set_chain_params(self, segment=0, seq_generic=False, seq_segment=None):
+    def set_chain_params(self, segment=0, seq_generic=False, seq_segment=None, seq_group=None):
+        """seq_group: (max_segments, min_groups) of fqgpu_ctx_set_seq_group, or max_segments alone."""
         flags = 1 if seq_generic else 0
         if seq_segment is not None:
             _check(lib().fqgpu_ctx_set_seq_segment(self.h, seq_segment), "set_seq_segment")
+        if seq_group is not None:
+            q, g = seq_group if isinstance(seq_group, tuple) else (seq_group, 0)
+            _check(lib().fqgpu_ctx_set_seq_group(self.h, q, g), "set_seq_group")
         _check(lib().fqgpu_ctx_set_chain_params(self.h, segment, flags), "set_chain_params")
 
     def set_index_stride(self, symbols):

@@ -341,6 +341,8 @@ extern "C" int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual
   }
   rc = fq_probe_lds_atomic_order(ctx->stream, &ctx->lds_atomics_ordered);
   if (getenv("FQGPU_NO_LDS_ATOMIC_RANK")) ctx->lds_atomics_ordered = false;  // force the ballot kernel
+  if (const char *e = getenv("FQGPU_SEQ_GROUP")) ctx->seq_group = (unsigned)atoi(e);  // experiments
+  if (const char *e = getenv("FQGPU_SEQ_GROUP_MIN")) ctx->seq_group_min = (unsigned)atoi(e);
   if (!rc) rc = upload_tables(ctx, 0, seq_ft);
   if (!rc) rc = upload_tables(ctx, 1, qual_ft);
   if (rc) { fqgpu_ctx_destroy(ctx); return rc; }
@@ -373,6 +375,13 @@ extern "C" int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsi
     ctx->seg_len = segment;
   }
   ctx->seq_generic = (flags & FQGPU_CHAIN_SEQ_GENERIC) ? 1 : 0;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_ctx_set_seq_group(fqgpu_ctx *ctx, unsigned max_segments, unsigned min_groups) {
+  if (!ctx) return FQGPU_E_ARG;
+  ctx->seq_group = max_segments ? max_segments : 8u;
+  ctx->seq_group_min = min_groups ? min_groups : 16u;
   return FQGPU_OK;
 }
 

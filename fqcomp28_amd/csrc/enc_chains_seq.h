@@ -57,6 +57,7 @@ constexpr unsigned SETS_WAVES = 8;          // segments (waves) per workgroup in
 constexpr unsigned SETS_WAVES2 = 16;        // ... with the 64 KB two-symbol table (one workgroup per CU)
 constexpr unsigned SETS_ROUNDS = 4;         // a workgroup owns WAVES * SETS_ROUNDS segments, handed out to its waves one by one
 constexpr unsigned SETS_MAX_CLASSES = 512;  // above this a segment keeps carrying every state
+constexpr unsigned SETS_MAX_GROUP = 16;      // segments a wave walks in one go, at most
 constexpr unsigned SETS_BLOCK = 1024;       // symbols per 16-byte-per-lane load; S is a multiple
 
 struct SetsWaveLds {
@@ -67,12 +68,19 @@ struct SetsWaveLds {
   uint16_t m[SETS_MAX_CLASSES];      // first-level class -> current class
 };
 
+// Segments a k_seq_setfunc wave walks in one go ("group") for a chain with nf functions: as many
+// as keep >= gmin groups in the chain (a workgroup's waves all busy), at most qmax.
+__device__ __forceinline__ unsigned seq_group_of(unsigned nf, unsigned qmax, unsigned gmin) {
+  return min(max((nf + gmin - 1) / gmin, 1u), qmax);
+}
+
 // plan[]: fitem_base[B+1] (step A workgroups before every context) | fseg_base[B+1] (functions
 // before every context) | seg_base[B+1] (segments) | eitem_base[B+1] (step C waves)
 constexpr unsigned SEGPLAN_WORDS = 4 * (SeqModel::B + 1) + 4;  // + the work counter of step A
 
 __global__ void __launch_bounds__(256)
-k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, unsigned wpg, uint32_t *__restrict__ plan) {
+k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, unsigned qmax, unsigned gmin, unsigned wpg,
+              uint32_t *__restrict__ plan) {
   constexpr unsigned B = SeqModel::B;
   __shared__ unsigned s_nseg[B];
   const unsigned c = threadIdx.x;
@@ -81,15 +89,15 @@ k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, unsigned wpg, uin
   __syncthreads();
   unsigned fi = 0, fs = 0, sg = 0, ei = 0;
   for (unsigned o = 0; o < c; o++) {
-    const unsigned ns = s_nseg[o], nf = ns ? ns - 1 : 0;
-    fi += (nf + wpg - 1) / wpg; fs += nf; sg += ns; ei += (ns + 63) / 64;
+    const unsigned ns = s_nseg[o], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin), nl = (nf + Q - 1) / Q;
+    fi += (nl + wpg - 1) / wpg; fs += nf; sg += ns; ei += (ns + 63) / 64;
   }
   uint32_t *fitem = plan, *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *eitem = plan + 3 * (B + 1);
   fitem[c] = fi; fseg[c] = fs; seg[c] = sg; eitem[c] = ei;
   if (c == 0) plan[4 * (B + 1)] = 0;  // step A's work counter
   if (c == B - 1) {
-    const unsigned ns = s_nseg[c], nf = ns ? ns - 1 : 0;
-    fitem[B] = fi + (nf + wpg - 1) / wpg; fseg[B] = fs + nf; seg[B] = sg + ns; eitem[B] = ei + (ns + 63) / 64;
+    const unsigned ns = s_nseg[c], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin), nl = (nf + Q - 1) / Q;
+    fitem[B] = fi + (nl + wpg - 1) / wpg; fseg[B] = fs + nf; seg[B] = sg + ns; eitem[B] = ei + (ns + 63) / 64;
   }
 }
 
@@ -253,8 +261,8 @@ template <unsigned PER0, bool TWO>
 __global__ void __launch_bounds__((TWO ? SETS_WAVES2 : SETS_WAVES) * 64)
 k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
               const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs,
-              const uint16_t *__restrict__ next, unsigned next_stride, unsigned S, unsigned fstride,
-              uint16_t *__restrict__ fbuf, unsigned *__restrict__ work_counter) {
+              const uint16_t *__restrict__ next, unsigned next_stride, unsigned S, unsigned qmax, unsigned gmin,
+              unsigned rounds, unsigned fstride, uint16_t *__restrict__ fbuf, unsigned *__restrict__ work_counter) {
   constexpr unsigned WAVES = TWO ? SETS_WAVES2 : SETS_WAVES;
   extern __shared__ uint32_t lds[];  // next[4][size] (TWO: next2[16][size]) of this context
   __shared__ SetsWaveLds wl[WAVES];
@@ -264,7 +272,7 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
   SetsWaveLds &L = wl[wave];
   const char *tbase = reinterpret_cast<const char *>(lds);
-  const unsigned nblk = S / SETS_BLOCK, w_end = S / 4;
+  const unsigned sub_blocks = S / SETS_BLOCK;  // 1024-symbol loads per segment
   const unsigned n_items = fitem[B];
   unsigned loaded = 0xFFFFFFFFu;  // context whose table is in LDS
   // Persistent workgroups (one per CU, 125 KB of LDS with the two-symbol table): items are
@@ -285,12 +293,17 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
       loaded = c;
       __syncthreads();
     }
-    const unsigned nf = fseg[c + 1] - fseg[c];
-    // the item's segments [k0, k_end) of the chain go to whichever wave is free
-    const unsigned k0 = (item - fitem[c]) * (WAVES * SETS_ROUNDS), k_end = min(k0 + WAVES * SETS_ROUNDS, nf);
+    const unsigned nf = fseg[c + 1] - fseg[c], Q = seq_group_of(nf, qmax, gmin), nl = (nf + Q - 1) / Q;
+    // A wave walks a GROUP of up to Q consecutive segments in one go and writes the function
+    // "entry state of the group -> state behind segment j" at every segment boundary: the state
+    // sets keep shrinking along the group (one gather per step from ~2048 symbols on), while a
+    // fresh start pays ~1500 gathers for its first 2048 symbols.  The item's groups [k0, k_end)
+    // of the chain go to whichever wave is free.
+    const unsigned k0 = (item - fitem[c]) * (WAVES * rounds), k_end = min(k0 + WAVES * rounds, nl);
     const unsigned per = max(size >> 6, 1u), nw = max(size >> 5, 1u);
     for (unsigned k = k0 + wave; k < k_end;) {
-      const uint4 *gseg = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)k * S);
+      const unsigned s0 = k * Q, nblk = min(Q, nf - s0) * sub_blocks, w_end = nblk * (SETS_BLOCK / 4);
+      const uint4 *gseg = reinterpret_cast<const uint4 *>(sorted_sym + arrays[B + c] + (size_t)s0 * S);
 
       // level 0: every state; lane l carries states l, l + 64, ...
       unsigned x0[PER0];
@@ -355,13 +368,14 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
           }
         }
         cur = nxt;
-      }
-      // F[entry] = exit, both as (state - size) * 2
-      uint16_t *f = fbuf + (size_t)(fseg[c] + k) * fstride;
+        if ((blk + 1) % sub_blocks == 0) {  // F[entry] = state here, both as (state - size) * 2
+          uint16_t *f = fbuf + (size_t)(fseg[c] + s0 + blk / sub_blocks) * fstride;
 #pragma unroll
-      for (unsigned j = 0; j < PER0; j++) {
-        const unsigned xi = lane + 64u * j;
-        if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
+          for (unsigned j = 0; j < PER0; j++) {
+            const unsigned xi = lane + 64u * j;
+            if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
+          }
+        }
       }
       unsigned nk = 0;
       if (lane == 0) nk = atomicAdd(&s_next, 1u);
@@ -370,18 +384,29 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
   }
 }
 
-// Step B: entry state of every segment of every chain
+// Step B: entry state of every segment of every chain.  The functions of a group all start at
+// the group's entry state, so a group costs one round of independent 2-byte loads.
 __global__ void __launch_bounds__(256)
-k_seq_resolve(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, unsigned fstride,
-              uint16_t *__restrict__ entry) {
+k_seq_resolve(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned qmax,
+              unsigned gmin, uint16_t *__restrict__ entry) {
   constexpr unsigned B = SeqModel::B;
   const uint32_t *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1);
   const unsigned c = threadIdx.x;
-  const unsigned ns = seg[c + 1] - seg[c];
+  const unsigned ns = seg[c + 1] - seg[c], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin);
   unsigned xo = 0;  // FSE_initCState: state = size
-  for (unsigned k = 0; k < ns; k++) {
-    entry[seg[c] + k] = (uint16_t)xo;
-    if (k + 1 < ns) xo = fbuf[(size_t)(fseg[c] + k) * fstride + (xo >> 1)];
+  for (unsigned s0 = 0; s0 < ns; s0 += Q) {
+    entry[seg[c] + s0] = (uint16_t)xo;
+    unsigned v[SETS_MAX_GROUP];
+#pragma unroll
+    for (unsigned j = 0; j < SETS_MAX_GROUP; j++)
+      v[j] = j < Q && s0 + j < nf ? (unsigned)fbuf[(size_t)(fseg[c] + s0 + j) * fstride + (xo >> 1)] : 0u;
+    unsigned nx = xo;
+#pragma unroll
+    for (unsigned j = 0; j < SETS_MAX_GROUP; j++)
+      if (j < Q && s0 + j < nf) {
+        if (j + 1 < Q) entry[seg[c] + s0 + j + 1] = (uint16_t)v[j]; else nx = v[j];
+      }
+    xo = nx;
   }
 }
 

@@ -182,9 +182,11 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     const unsigned next_stride = 4u << tab.max_log;
     const bool two = tab.next2 != nullptr;  // two-symbol tables exist up to log 11
     const unsigned wpg = two ? SETS_WAVES2 : SETS_WAVES;
-    const unsigned max_fitems = seq_max_segs / (wpg * SETS_ROUNDS) + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
+    const unsigned Q = min(max(ctx->seq_group, 1u), SETS_MAX_GROUP), gmin = max(ctx->seq_group_min, 1u);
+    const unsigned rounds = max(SETS_ROUNDS / Q, 1u);
+    const unsigned max_fitems = seq_max_segs / (wpg * rounds) + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
     static const bool dbg_skip = getenv("FQGPU_DEBUG_SKIP_SEQ_CHAIN") != nullptr;  // timing experiment only: wrong output
-    if (!dbg_off) hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, wpg * SETS_ROUNDS, plan);
+    if (!dbg_off) hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, Q, gmin, wpg * rounds, plan);
     FQ_SPAN_END();
     FQ_SPAN_BEGIN("seq.setfunc");
     if (!dbg_skip) {
@@ -192,14 +194,14 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
       } else if (two)
         hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(min(max_fitems, ctx->n_cus)), dim3(SETS_WAVES2 * 64),
                            32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2,
-                           4 * next_stride, seq_S, seq_fstride, fbuf, plan + 4 * (B + 1));
+                           4 * next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 4 * (B + 1));
       else
         hipLaunchKernelGGL((k_seq_setfunc<64, false>), dim3(min(max_fitems, 2 * ctx->n_cus)), dim3(SETS_WAVES * 64),
                            8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1,
-                           next_stride, seq_S, seq_fstride, fbuf, plan + 4 * (B + 1));
+                           next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 4 * (B + 1));
       FQ_SPAN_END();
       FQ_SPAN_BEGIN("seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
-      if (!dbg_off) hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, entry);
+      if (!dbg_off) hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, Q, gmin, entry);
       FQ_SPAN_END();
       FQ_SPAN_BEGIN("seq.chains");  dbg_off = (dbg_mask & 8u) != 0;
       if (!dbg_off) hipLaunchKernelGGL(k_seq_emit, dim3(max_eitems), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),

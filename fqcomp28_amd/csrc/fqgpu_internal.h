@@ -134,6 +134,8 @@ struct fqgpu_ctx {
   unsigned seg_len = 4096;       // segment of the generic chain kernels
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
   unsigned seq_segment = 0;      // segment length of the sequence chain kernels (0 = default)
+  unsigned seq_group = 8;        // segments a k_seq_setfunc wave walks in one go, at most (<= SETS_MAX_GROUP)
+  unsigned seq_group_min = 16;   // ... as long as a chain keeps this many groups (one per wave of a workgroup)
   bool lds_atomics_ordered = false;  // probed at creation: k_scatter may rank with LDS atomics
   unsigned index_stride = 1u << 20;  // symbols between the snapshots of a decode index
   unsigned n_cus = 256;          // compute units of the device (grid of the persistent kernels)

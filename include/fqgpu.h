@@ -94,6 +94,11 @@ int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned flags)
  * whose exact entry states come from per-segment state functions (0 = default 4096; rounded up
  * to a multiple of 1024).  Results never depend on it. */
 int fqgpu_ctx_set_seq_segment(fqgpu_ctx *ctx, unsigned symbols);
+/* A wave of the segment-function kernel walks up to max_segments consecutive segments in one go
+ * (the state sets keep shrinking along the way; 1..16, 0 = default 8), as long as the chain still
+ * splits into min_groups such groups (0 = default 16, the waves of a workgroup).  Results never
+ * depend on it. */
+int fqgpu_ctx_set_seq_group(fqgpu_ctx *ctx, unsigned max_segments, unsigned min_groups);
 /* Number of blocks the handle keeps in flight (encode lanes, 1..8, default 4): each
  * fqgpu_dblock_encode goes to the next lane (own HIP streams and scratch). */
 int fqgpu_ctx_set_lanes(fqgpu_ctx *ctx, unsigned lanes);

@@ -394,6 +394,25 @@ def _rewrite_bases(raw, recs, make):
     return raw
 
 
+@pytest.mark.parametrize("group", [(1, 1), (3, 1), (8, 1), (16, 4)])
+@pytest.mark.parametrize("bases", ["uniform", "all_A"])
+def test_sequence_segment_groups_are_exact(F, bases, group):
+    """A wave of k_seq_setfunc walks a group of consecutive segments and writes one function per
+    segment boundary, all from the group's entry state; k_seq_resolve reads a group's functions in
+    one round.  Any group size (incl. ragged last groups, chains shorter than a group, and the
+    never-collapsing single-symbol context) gives the oracle's bits."""
+    raw, recs = _synth(F, 2, 6 << 20)
+    if bases == "all_A":
+        raw = _rewrite_bases(raw, recs, lambda n: np.zeros(n, dtype=np.int64))
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    ctx.set_chain_params(0, seq_segment=1024, seq_group=group)
+    g = ctx.encode_block(raw, recs)
+    assert_same_encoding(g, e)
+    ctx.close()
+
+
 @pytest.mark.parametrize("bases", ["uniform", "skewed", "markov", "all_A", "mostly_A"])
 @pytest.mark.parametrize("segment", [1024, 4096, 20000, 1 << 30])
 def test_sequence_segment_functions_are_exact(F, bases, segment):
