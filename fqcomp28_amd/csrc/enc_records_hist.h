@@ -3,27 +3,36 @@
 // ------------------------------------------------------------------ record-level kernels
 
 // readlens + N count per record (replaceAndEncodeNs, src/fse_sequence.cpp:35-51, first half).
-// One wave per record, lanes stride the bases.
+// Sixteen lanes per record, 16 bases per lane and load: four records per wave and round, one
+// round trip for a read of up to 256 bases.
+struct __attribute__((packed)) FqBytes16 { uint32_t w[4]; };  // 16 bytes at any address
 __global__ void __launch_bounds__(256)
 k_readlens_ncount(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R,
                   uint16_t *__restrict__ readlens, uint16_t *__restrict__ n_count,
                   uint32_t *__restrict__ n_cnt32, uint32_t *__restrict__ lens32) {
   const unsigned waves = (gridDim.x * blockDim.x) >> 6;
-  const unsigned lane = fq_lane();
-  for (unsigned r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < R; r += waves) {
-    const fqgpu_rec rec = recs[r];
+  const unsigned lane = fq_lane(), sub = lane >> 4, l = lane & 15u;
+  for (unsigned r0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4; r0 < R; r0 += waves * 4) {
+    const unsigned r = r0 + sub;
+    const bool on = r < R;
+    const fqgpu_rec rec = recs[on ? r : R - 1];
+    const unsigned len = on ? rec.len : 0u;
     const uint8_t *s = raw + rec.seq_off;
     unsigned cnt = 0;
-    for (unsigned base = 0; base < rec.len; base += 64) {
-      const unsigned i = base + lane;
-      const bool isn = i < rec.len && s[i] == 'N';
-      cnt += (unsigned)__popcll(__ballot(isn));
+    for (unsigned off = l * 16; off < len; off += 256) {  // (the block has 64 spare bytes behind raw)
+      const FqBytes16 v = *reinterpret_cast<const FqBytes16 *>(s + off);
+      const unsigned live = min(16u, len - off);
+#pragma unroll
+      for (unsigned i = 0; i < 16; i++)
+        cnt += (i < live && ((v.w[i >> 2] >> (8 * (i & 3))) & 0xFFu) == 'N') ? 1u : 0u;
     }
-    if (lane == 0) {
-      readlens[r] = (uint16_t)rec.len;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);  // stays inside the 16 lanes
+    if (l == 0 && on) {
+      readlens[r] = (uint16_t)len;
       n_count[r] = (uint16_t)cnt;
       n_cnt32[r] = cnt;
-      lens32[r] = rec.len;
+      lens32[r] = len;
     }
   }
 }

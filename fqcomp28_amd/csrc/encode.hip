@@ -378,9 +378,10 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
   uint32_t *rec_start = lane.rec_start.as<uint32_t>();
 
   FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), st));
-  const unsigned rec_blocks = (unsigned)min((size_t)(R + 3) / 4, (size_t)8192);
+  const unsigned rec_blocks = (unsigned)min((size_t)(R + 3) / 4, (size_t)8192);  // k_npos: a wave per record
+  const unsigned len_blocks = (unsigned)min((size_t)(R + 15) / 16, (size_t)4096);  // four records per wave
   FQ_SPAN_BEGIN("records");
-  hipLaunchKernelGGL(k_readlens_ncount, dim3(rec_blocks), dim3(256), 0, st, b->raw, b->recs, R,
+  hipLaunchKernelGGL(k_readlens_ncount, dim3(len_blocks), dim3(256), 0, st, b->raw, b->recs, R,
                      b->readlens, b->n_count, n_cnt32, lens32);
   if ((rc = fq_scan2_u32_to_u32(st, lens32, n_cnt32, R, rec_start, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
   hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
