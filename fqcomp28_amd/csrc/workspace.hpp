@@ -9,8 +9,12 @@
 //   DecompressionWorkspace::decodeChunk            src/workspace.h:112, src/workspace.cpp:47-88
 //   Workspace::compressBoundSequence/Quality       src/workspace.h:21-35
 //   FSE_{Sequence,Quality}::calculateFreqTable     src/fse_sequence.h:72, src/fse_quality.h:50
-// Only the seq/qual FSE part of a block is coded here (header tokeniser and
-// the libbsc pass over the misc streams stay with the host application).  Error behaviour:
+//   CompressionWorkspace::encodeHeader / DecompressionWorkspace::decodeHeader   src/workspace.cpp:95-157
+// The seq/qual FSE streams are coded on the GPU; the header fields are tokenised and delta-coded
+// on the host (headers.hpp).  The misc streams (readlens, n_count, n_pos,
+// header fields) are left as they are BEFORE the reference's libbsc pass (src/workspace.cpp:176-236:
+// libbsc's source is absent); cbs.original_size carries their sizes as that pass would record them.
+// Error behaviour:
 // the reference asserts / silently returns size 0; this shim throws std::runtime_error with
 // fqgpu_strerror().  Header-only; link with libfqgpu.so.
 #pragma once
@@ -27,6 +31,7 @@
 #include <vector>
 
 #include "../../include/fqgpu.h"
+#include "headers.hpp"
 
 namespace fqcomp28 {
 
@@ -54,8 +59,13 @@ struct FastqChunk {  // src/defs.h:34-52
   }
 };
 
-struct cb_original_sizes_t {  // src/compressed_buffers.h:10-32 (header fields left to the host)
+struct cb_original_sizes_t {  // src/compressed_buffers.h:10-32
+  std::vector<headers::FieldStorage::sizes> header_fields;
   uint32_t total = 0, readlens = 0, n_records = 0, n_count = 0, n_pos = 0;
+  void clear() {
+    total = readlens = n_records = n_count = n_pos = 0;
+    for (auto &sz : header_fields) sz = {};
+  }
 };
 
 struct CompressedBuffers {  // src/compressed_buffers.h:34-69
@@ -63,13 +73,24 @@ struct CompressedBuffers {  // src/compressed_buffers.h:34-69
   cb_original_sizes_t original_size;
   uint32_t chunk_idx = 0;
   /* like the reference, clear() does NOT clear n_count / n_pos */
-  virtual void clear() { seq.clear(); qual.clear(); readlens.clear(); original_size = {}; }
+  virtual void clear() { seq.clear(); qual.clear(); readlens.clear(); original_size.clear(); }
   virtual ~CompressedBuffers() = default;
 };
-struct CompressedBuffersDst : CompressedBuffers {};
+struct CompressedBuffersDst : CompressedBuffers {
+  std::vector<headers::FieldStorageDst> header_fields;
+  void clear() override {
+    CompressedBuffers::clear();
+    for (auto &hf : header_fields) hf.clear();
+  }
+};
 struct CompressedBuffersSrc : CompressedBuffers {
+  std::vector<headers::FieldStorageSrc> header_fields;
   struct { std::size_t n_count = 0, n_pos = 0; } index;  // src/compressed_buffers.h:90-93
-  void clear() override { CompressedBuffers::clear(); index = {}; }
+  void clear() override {
+    CompressedBuffers::clear();
+    for (auto &hf : header_fields) hf.clear();
+    index = {};
+  }
 };
 
 inline void fqgpuCheck(int rc, const char *what) {
@@ -80,13 +101,16 @@ inline void fqgpuCheck(int rc, const char *what) {
 struct DatasetMeta {
   /** used by the host's header coder for delta-ing the first header of each chunk (src/prepare.h:30) */
   std::string first_header;
+  headers::HeaderFormatSpeciciation header_fmt;  // src/prepare.h:31
   std::unique_ptr<std::byte[]> ft_seq{new std::byte[FQGPU_SEQ_FT_BYTES]};
   std::unique_ptr<std::byte[]> ft_qual{new std::byte[FQGPU_QUAL_FT_BYTES]};
   DatasetMeta() = default;
-  explicit DatasetMeta(std::string_view header) : first_header(header) {}
+  explicit DatasetMeta(std::string_view header)
+      : first_header(header), header_fmt(headers::HeaderFormatSpeciciation::fromHeader(first_header)) {}
   /** DatasetMeta(const FastqChunk&) (src/prepare.h:23-27): dataset analysis on the GPU */
   explicit DatasetMeta(const FastqChunk &chunk, int device = 0)
       : first_header(chunk.records.empty() ? std::string_view() : chunk.records.front().header()) {
+    if (!first_header.empty()) header_fmt = headers::HeaderFormatSpeciciation::fromHeader(first_header);
     std::vector<fqgpu_rec> recs = toRecordTable(chunk);
     fqgpuCheck(fqgpu_freq_tables(device, reinterpret_cast<const uint8_t *>(chunk.raw_data.data()),
                                  chunk.raw_data.size(), recs.data(), recs.size(), ft_seq.get(),
@@ -140,13 +164,19 @@ public:
   static std::size_t compressBoundQuality(std::size_t n) { return fqgpu_bound_qual(n); }
 
 protected:
-  explicit Workspace(const DatasetMeta *meta, int device) : meta_(meta) {
+  explicit Workspace(const DatasetMeta *meta, int device)
+      : meta_(meta), fmt_(meta->header_fmt), first_header_fields_(headers::fromHeader(meta->first_header, fmt_)) {
     fqgpuCheck(fqgpu_ctx_create(device, meta->ft_seq.get(), meta->ft_qual.get(), &ctx_), "Workspace");
   }
+  /** every chunk codes its first header against the dataset's first header (src/workspace.cpp:90-93) */
+  void startNewChunk() { prev_header_fields_ = first_header_fields_; }
   ~Workspace() { fqgpu_ctx_destroy(ctx_); }
   Workspace(const Workspace &) = delete;
   Workspace &operator=(const Workspace &) = delete;
   const DatasetMeta *const meta_;
+  const headers::HeaderFormatSpeciciation fmt_;
+  const headers::header_fields_t first_header_fields_;
+  headers::header_fields_t prev_header_fields_;
   fqgpu_ctx *ctx_ = nullptr;
 };
 
@@ -162,6 +192,12 @@ public:
     cbs.seq.resize(compressBoundSequence(chunk.tot_reads_length));
     cbs.qual.resize(compressBoundQuality(chunk.tot_reads_length));
     cbs.readlens.resize(R * sizeof(readlen_t));
+    cbs.header_fields.resize(fmt_.n_fields());
+    cbs.original_size.header_fields.resize(fmt_.n_fields());
+    for (auto &field : cbs.header_fields) field.clear();
+    startNewChunk();
+    for (const FastqRecord &r : chunk.records) headers::encodeHeader(r.header(), fmt_, prev_header_fields_, cbs.header_fields);
+    for (std::size_t i = 0; i < fmt_.n_fields(); ++i) cbs.original_size.header_fields[i] = cbs.header_fields[i].originalSizes();
     std::vector<fqgpu_rec> recs = DatasetMeta::toRecordTable(chunk);
     std::vector<uint16_t> n_count(R), n_pos(chunk.tot_reads_length);
     std::size_t seq_len = 0, qual_len = 0, n_pos_len = 0;
@@ -196,9 +232,33 @@ class DecompressionWorkspace : public Workspace {
 public:
   explicit DecompressionWorkspace(const DatasetMeta *meta, int device = 0) : Workspace(meta, device) {}
 
-  /** Second pass of decodeChunk: chunk.raw_data / chunk.records have been laid out by the
-   *  host's first pass (headers decoded, seqp/qualp/length set: src/workspace.cpp:62-80) */
+  /** Both passes of decodeChunk (src/workspace.cpp:47-88): the first lays the chunk out
+   *  (headers decoded on the host, lengths from readlens, '+' and newlines), the second fills the
+   *  sequence and quality lines on the GPU */
   void decodeChunk(FastqChunk &chunk, CompressedBuffersSrc &cbs) {
+    chunk.clear();  // prepareFastqChunk (src/workspace.h:127-133)
+    chunk.idx = cbs.chunk_idx;
+    chunk.raw_data.resize(cbs.original_size.total);
+    chunk.records.resize(cbs.original_size.n_records);
+    startNewChunk();
+    if (cbs.header_fields.size() != fmt_.n_fields()) throw std::invalid_argument("decodeChunk: header field streams do not match the format");
+    if (cbs.readlens.size() < chunk.records.size() * sizeof(readlen_t)) throw std::invalid_argument("decodeChunk: readlens too short");
+    char *dst = chunk.raw_data.data();
+    char *const end = dst + chunk.raw_data.size();
+    for (std::size_t i = 0, E = chunk.records.size(); i < E; ++i) {
+      FastqRecord &r = chunk.records[i];
+      std::memcpy(&r.length, cbs.readlens.data() + sizeof(readlen_t) * i, sizeof(readlen_t));
+      r.headerp = dst;
+      r.header_length = static_cast<readlen_t>(decodeHeaderChecked(dst, end, cbs));
+      dst += r.header_length;
+      if (static_cast<std::size_t>(end - dst) < 2u * r.length + 5u) throw std::out_of_range("decodeChunk: original_size.total too small");
+      *dst++ = '\n';
+      r.seqp = dst;  dst += r.length;  *dst++ = '\n';
+      *dst++ = '+';  *dst++ = '\n';
+      r.qualp = dst; dst += r.length;  *dst++ = '\n';
+      chunk.tot_reads_length += r.length;
+      chunk.headers_length += r.header_length;
+    }
     std::vector<fqgpu_rec> recs = DatasetMeta::toRecordTable(chunk);
     fqgpuCheck(fqgpu_decode_block(ctx_, reinterpret_cast<const uint8_t *>(cbs.seq.data()), cbs.seq.size(),
                                   reinterpret_cast<const uint8_t *>(cbs.qual.data()), cbs.qual.size(),
@@ -209,6 +269,24 @@ public:
                                   reinterpret_cast<uint8_t *>(chunk.raw_data.data()), chunk.raw_data.size()),
                "decodeChunk");
   }
+
+private:
+  /** decodeHeader with the output bound checked: near the end of the chunk the header goes through
+   *  a local buffer, since the field decoders may write up to FIELDLEN_MAX bytes per field */
+  unsigned decodeHeaderChecked(char *dst, char *end, CompressedBuffersSrc &cbs) {
+    const std::size_t worst = 1 + fmt_.n_fields() * (headers::FIELDLEN_MAX + 1);
+    if (static_cast<std::size_t>(end - dst) >= worst) return headers::decodeHeader(dst, fmt_, prev_header_fields_, cbs.header_fields);
+    tail_.resize(worst);
+    const unsigned n = headers::decodeHeader(tail_.data(), fmt_, prev_header_fields_, cbs.header_fields);
+    if (static_cast<std::size_t>(end - dst) < n) throw std::out_of_range("decodeChunk: original_size.total too small");
+    std::memcpy(dst, tail_.data(), n);
+    // string fields of the previous header must point at bytes that stay: re-anchor them in dst
+    headers::header_fields_t anchored = headers::fromHeader(std::string_view(dst, n), fmt_);
+    for (std::size_t i = 0; i < anchored.size(); ++i)
+      if (fmt_.field_types[i] == headers::FieldType::STRING) prev_header_fields_[i] = anchored[i];
+    return n;
+  }
+  std::vector<char> tail_;
 };
 
 /** FastqReader::parseRecords (src/fastq_io.cpp:67-125) on top of fqgpu_parse_fastq */

@@ -29,6 +29,13 @@ static CompressedBuffersSrc convertToSrcBuffers(CompressedBuffersDst &&in) {  //
   src.n_pos = std::move(in.n_pos);
   src.index.n_pos = src.n_pos.size();
   src.readlens = std::move(in.readlens);
+  src.chunk_idx = in.chunk_idx;
+  src.header_fields.resize(in.header_fields.size());
+  for (std::size_t i = 0; i < in.header_fields.size(); ++i) {
+    src.header_fields[i].isDifferentFlag = std::move(in.header_fields[i].isDifferentFlag);
+    src.header_fields[i].content = std::move(in.header_fields[i].content);
+    src.header_fields[i].contentLength = std::move(in.header_fields[i].contentLength);
+  }
   return src;
 }
 
@@ -50,16 +57,33 @@ static int encodeChunkRoundTrip(const char *path) {
   CHECK(cbs.seq.size() <= Workspace::compressBoundSequence(chunk_in.tot_reads_length));
   CHECK(cbs.n_count.size() == 2 * chunk_in.records.size() * sizeof(readlen_t));
 
-  // first pass of decodeChunk (host side): skeleton with headers, '+' and newlines
-  FastqChunk chunk_out;
-  chunk_out.raw_data = original;
-  parseRecords(chunk_out);
-  for (auto &r : chunk_out.records) {
-    std::memset(r.seqp, '?', r.length);
-    std::memset(r.qualp, '?', r.length);
+  // the header fields went through the tokeniser: one stream set per field of the first header,
+  // flags for every record of a STRING field, four bytes per record of a NUMERIC one
+  const auto fmt = headers::HeaderFormatSpeciciation::fromHeader(chunk_in.records.front().header());
+  CHECK(fmt == meta.header_fmt);
+  CHECK(cbs.header_fields.size() == fmt.n_fields());
+  CHECK(cbs.original_size.header_fields.size() == fmt.n_fields());
+  for (std::size_t i = 0; i < fmt.n_fields(); ++i) {
+    const auto &f = cbs.header_fields[i];
+    CHECK(f.originalSizes() == cbs.original_size.header_fields[i]);
+    if (fmt.field_types[i] == headers::FieldType::STRING) {
+      CHECK(f.isDifferentFlag.size() == chunk_in.records.size());
+    } else {
+      CHECK(f.isDifferentFlag.empty() && f.contentLength.empty());
+      CHECK(f.content.size() == chunk_in.records.size() * sizeof(headers::numeric_t));
+    }
   }
+
+  // decodeChunk from the buffers alone: both passes (layout + headers on the host, reads on the GPU)
+  FastqChunk chunk_out;
+  chunk_out.raw_data.assign(7, 'x');  // stale contents are dropped
   CompressedBuffersSrc src = convertToSrcBuffers(std::move(cbs));
   dwksp.decodeChunk(chunk_out, src);
+  for (const auto &f : src.header_fields) {  // every stream fully consumed
+    CHECK(f.index.isDifferentPos == f.isDifferentFlag.size());
+    CHECK(f.index.contentPos == f.content.size());
+    CHECK(f.index.contentLengthPos == f.contentLength.size());
+  }
 
   CHECK(chunk_out.records.size() == chunk_in.records.size());
   FastqChunk ref;
