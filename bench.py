@@ -19,7 +19,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # 4 blocks in flight x (seq, qual, long-chain) streams
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # up to 8 blocks in flight x (seq, qual) streams, one hardware queue each
 
 import numpy as np  # noqa: E402
 

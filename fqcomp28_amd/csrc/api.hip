@@ -10,9 +10,9 @@
 
 // The encode lanes use up to 16 streams (two per block in flight: sequence and quality pipelines).  ROCm maps streams onto
 // GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
-// run back to back; ask for 12 before the runtime initialises (no effect if the host
+// run back to back; ask for 24 before the runtime initialises (no effect if the host
 // application already initialised HIP or set the variable itself).
-__attribute__((constructor)) static void fq_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+__attribute__((constructor)) static void fq_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_hip_msg[256] = "";
