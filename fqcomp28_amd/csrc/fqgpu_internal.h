@@ -131,7 +131,7 @@ struct fqgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;  // uploads, decode
   DevTables tab[2];
-  unsigned seg_len = 4096;       // segment of the generic chain kernels
+  unsigned seg_len = 0;          // segment of the generic chain kernels (0 = by block size: 1024..4096)
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
   unsigned seq_segment = 0;      // segment length of the sequence chain kernels (0 = default)
   unsigned seq_group = 8;        // segments a k_seq_setfunc wave walks in one go, at most (<= SETS_MAX_GROUP)

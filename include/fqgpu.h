@@ -91,7 +91,7 @@ void fqgpu_ctx_destroy(fqgpu_ctx *ctx);
 #define FQGPU_CHAIN_SEQ_GENERIC 1u
 int fqgpu_ctx_set_chain_params(fqgpu_ctx *ctx, unsigned segment, unsigned flags);
 /* Segment length, in symbols, of the sequence chain kernels: every chain is cut into segments
- * whose exact entry states come from per-segment state functions (0 = default 4096; rounded up
+ * whose exact entry states come from per-segment state functions (0 = default: 4096, 2048 or 1024 by block size; rounded up
  * to a multiple of 1024).  Results never depend on it. */
 int fqgpu_ctx_set_seq_segment(fqgpu_ctx *ctx, unsigned symbols);
 /* A wave of the segment-function kernel walks up to max_segments consecutive segments in one go
