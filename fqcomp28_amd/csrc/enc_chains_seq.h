@@ -43,21 +43,24 @@ __device__ __forceinline__ unsigned reset_state(const LdsCTable &t, unsigned sym
 // after 128 symbols for exactly uniform counts, a few dozen otherwise), because every
 // transition x -> stateTable[(x >> nb) + delta] merges the states that share x >> nb.  The
 // chain of a context is therefore cut into segments of S symbols and coded in three exact steps:
-//  (A) k_seq_setfunc: one wave per segment computes F: entry state -> exit state for EVERY
-//      possible entry state.  It starts with all 2^log states spread over the lanes, and at a
-//      few points (after 4, 16, 48, 128, 512, 2048, ... symbols) replaces the states it carries by
-//      the distinct ones ("classes"), remembering which class every entry state fell into.
-//      After the first hundred symbols a step costs 1-3 LDS gathers per wave for 64 lanes.
-//  (B) k_seq_resolve: entry state of every segment, x <- F_k[x] segment after segment.
+//  (A) k_seq_setfunc: a wave computes F: entry state -> exit state for EVERY possible entry
+//      state.  It starts with all 2^log states spread over the lanes, and at a few points (after
+//      4, 16, 48, 128, 512, 2048, ... symbols) replaces the states it carries by the distinct
+//      ones ("classes"), remembering which class every entry state fell into.  After the first
+//      hundred symbols a step costs 1-3 LDS gathers per wave for 64 lanes, from ~2048 symbols on
+//      one -- so the wave walks on through a GROUP of up to 8 consecutive segments and writes
+//      the function "entry state of the group -> state here" at every segment boundary.
+//  (B) k_seq_resolve: entry state of every segment; a group's functions all start at the group's
+//      entry state (one round of independent loads), x <- F_last[x] from group to group.
 //  (C) k_seq_emit: every lane walks ONE segment from its now-known entry state and writes the
 //      packed (nb, bits) of every symbol; 64 segments of a context per wave.
 // All three read the context's one-symbol transition table next[s][x] from LDS (tables.hip
 // builds it once per handle).  Exact by construction: no speculation, nothing to verify.
 constexpr unsigned SETS_WAVES = 8;          // segments (waves) per workgroup in step A, one-symbol table
 constexpr unsigned SETS_WAVES2 = 16;        // ... with the 64 KB two-symbol table (one workgroup per CU)
-constexpr unsigned SETS_ROUNDS = 4;         // a workgroup owns WAVES * SETS_ROUNDS segments, handed out to its waves one by one
+constexpr unsigned SETS_ROUNDS = 4;         // a workgroup owns WAVES * max(SETS_ROUNDS / group, 1) groups, handed out to its waves one by one
 constexpr unsigned SETS_MAX_CLASSES = 512;  // above this a segment keeps carrying every state
-constexpr unsigned SETS_MAX_GROUP = 16;      // segments a wave walks in one go, at most
+constexpr unsigned SETS_MAX_GROUP = 16;     // segments a wave walks in one go, at most
 constexpr unsigned SETS_BLOCK = 1024;       // symbols per 16-byte-per-lane load; S is a multiple
 
 struct SetsWaveLds {
