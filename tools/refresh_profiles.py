@@ -26,7 +26,7 @@ for n in sorted(fa, key=lambda k: -(fa[k][1] * 2 + wa.get(k, [0, 0])[1])):
     out.append((n, c, fk, wk, (2 * fk + wk) * 1024 / 1e6))
 with open(R + "profiles/r01_pmc_hbm_traffic_per_launch.csv", "w") as f:
     f.write("kernel,launches,FETCH_SIZE_KB_per_launch_raw,WRITE_SIZE_KB_per_launch,HBM_MB_per_launch_fetch_doubled\n")
-    for o in out: f.write("%s,%d,%.1f,%.1f,%.1f\n" % o)
+    for o in out: f.write("\"%s\",%d,%.1f,%.1f,%.1f\n" % o)
 skip = ("k_hist", "k_build", "k_normalize", "k_fill", "k_log", "k_reset", "k_probe")
 print("HBM MB per block:", sum(o[4] * o[1] for o in out if not o[0].startswith(skip)) / 8)
 for o in out[:12]: print("%-36s x%3d total(f x2) %8.1f MB  (fetch raw %7.1f write %7.1f)" % (o[0][:36], o[1], o[4], o[2] * 1.024 / 1e3, o[3] * 1.024 / 1e3))
@@ -47,7 +47,7 @@ if sq:
         for n, c in sorted(acc.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"]):
             if n.startswith(skip) or c["SQ_WAVE_CYCLES"] < 1e6: continue
             wc = c["SQ_WAVE_CYCLES"]
-            f.write("%s,%d,%.4g,%.1f,%.1f,%.1f,%.1f,%.4g,%.1f,%.4g\n" % (n, calls[n], wc, 100 * c["SQ_WAIT_ANY"] / wc, 100 * c["SQ_WAIT_INST_ANY"] / wc,
+            f.write("\"%s\",%d,%.4g,%.1f,%.1f,%.1f,%.1f,%.4g,%.1f,%.4g\n" % (n, calls[n], wc, 100 * c["SQ_WAIT_ANY"] / wc, 100 * c["SQ_WAIT_INST_ANY"] / wc,
                     100 * c["SQ_WAIT_INST_LDS"] / wc, 100 * c["SQ_ACTIVE_INST_ANY"] / wc, c["SQ_LDS_IDX_ACTIVE"],
                     100 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), c["SQ_BUSY_CYCLES"]))
 def last_json(path):
