@@ -137,6 +137,8 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
             StreamResult *res, int dbg) {
   __shared__ uint32_t hist[M::B];
   __shared__ RecCache rcache[4];  // one per wave
+  __shared__ uint8_t code_lut[256];  // fq_base_code of every byte value (sequence stream)
+  code_lut[threadIdx.x & 255u] = (uint8_t)fq_base_code(threadIdx.x & 255u);
   const unsigned tile = blockIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
@@ -172,7 +174,7 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
       const unsigned e = eb2 + lane;
       if (e < lim) {
         unsigned ctx, sym;
-        fq_ctx_from_bytes<M>(buf[slot], bp[slot], ctx, sym);
+        fq_ctx_from_bytes<M>(buf[slot], bp[slot], ctx, sym, code_lut);
         bad |= sym >= (unsigned)M::A;
         if (!(dbg & 2)) {
           if (M::STREAM == 0) ckey[e] = (uint16_t)(ctx | ((sym & 3u) << 8));

@@ -265,8 +265,10 @@ __device__ __forceinline__ unsigned long long fq_match_any(unsigned key, bool va
 }
 
 // A0 C1 G2 T3, everything else (N, which the coder treats as A: src/fse_sequence.cpp:44) -> 0
+// (three independent selects: the nested form compiles to a chain of exec-mask branches, five
+// times per symbol in K1)
 __device__ __forceinline__ unsigned fq_base_code(unsigned c) {
-  return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+  return (c == 'C' ? 1u : 0u) | (c == 'G' ? 2u : 0u) | (c == 'T' ? 3u : 0u);
 }
 
 // FSE_Quality::calcContext (src/fse_quality.h:40-44)
@@ -293,50 +295,62 @@ __device__ __forceinline__ unsigned fq_locate(const uint32_t *__restrict__ rec_s
 //     bases in front of p, nearest in bits 7:6, virtual T,C,C,T = 0xD7 before the read
 //   quality (QualityEncoder::encodeRecord src/fse_quality.cpp:5-53, L >= 3): context of p is
 //     calcContext(Q[p-1], Q[p-2], Q[p-3]) with zeros in front of the read
+// The symbol at position p of a read and the up to four (three) symbols in front of it, as the
+// raw bytes q .. q + 7 (q .. q + 3) of the line with q = max(p, 4) - 4 (max(p, 3) - 3): ONE
+// unaligned load per symbol instead of five (four) byte loads with an address computation each --
+// K1 is bound by instruction issue.
 struct SymBytes {
-  unsigned b[5];  // byte at p, p-1, ..., p-4 (0 where the position is in front of the read)
+  unsigned lo, hi;  // bytes q .. q + 3, q + 4 .. q + 7 (hi: sequence stream only)
 };
+struct __attribute__((packed)) FqU32x2 { uint32_t a, b; };  // eight bytes at any address
+struct __attribute__((packed)) FqU32x1 { uint32_t a; };
 
 template <class M>
 __device__ __forceinline__ SymBytes fq_load_sym_bytes(const uint8_t *__restrict__ raw, const fqgpu_rec &rec,
                                                       unsigned p, bool valid) {
-  // Unconditional loads from clamped positions (an idle lane has rec = {0, 0, 0}, p = 0 and reads
-  // byte 0 of the block): straight-line code lets the compiler keep several chunks' loads in
-  // flight; bytes in front of the read are ignored by fq_ctx_from_bytes (its p >= k tests).
+  // Unconditional loads (an idle lane has rec = {0, 0, 0}, p = 0 and reads the first bytes of the
+  // block; a read's last positions read a few bytes of what follows its line: the block has 64
+  // spare bytes behind raw): straight-line code lets the compiler keep several chunks' loads in flight.
   (void)valid;
+  constexpr unsigned K = M::STREAM == 0 ? 4u : 3u;
+  const uint8_t *s = raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off) + (p > K ? p - K : 0u);
   SymBytes r;
-  const uint8_t *s = raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off);
-  constexpr int N = M::STREAM == 0 ? 5 : 4;
-#pragma unroll
-  for (int k = 0; k < 5; k++) r.b[k] = k < N ? (unsigned)s[p >= (unsigned)k ? p - k : 0u] : 0u;
+  if (M::STREAM == 0) {
+    const FqU32x2 v = *reinterpret_cast<const FqU32x2 *>(s);
+    r.lo = v.a; r.hi = v.b;
+  } else {
+    r.lo = reinterpret_cast<const FqU32x1 *>(s)->a; r.hi = 0;
+  }
   return r;
 }
 
+// Context and symbol of position p from its window (fq_load_sym_bytes), without a branch or a
+// compare: K1 is bound by instruction issue, and "p >= k ? code(byte k) : virtual" compiled to four
+// exec-mask branches plus fifteen compare/select pairs per symbol.
+//  sequence: the bytes in front of the symbol are shifted to the top of a word (missing ones
+//            become 0), every byte goes through a 256-entry code table in LDS (exactly
+//            fq_base_code: 0 for anything but C, G, T -- so missing bytes add nothing), and the
+//            virtual bases in front of the read are 0xD7 >> 2 p (src/fse_sequence.h:22-24 applied p times)
+//  quality:  33 is subtracted from all four bytes at once (a byte < 33 borrows from its upper
+//            neighbour, but then the block is refused anyway: that byte is somebody's symbol >= 64)
 template <class M>
-__device__ __forceinline__ void fq_ctx_from_bytes(const SymBytes &r, unsigned p, unsigned &ctx, unsigned &sym) {
+__device__ __forceinline__ void fq_ctx_from_bytes(const SymBytes &r, unsigned p, unsigned &ctx, unsigned &sym,
+                                                  const uint8_t *code_lut) {
+  constexpr unsigned K = M::STREAM == 0 ? 4u : 3u;
+  const unsigned pq = min(p, K), sh = 8u * pq;  // the symbol is byte pq of the window
   if (M::STREAM == 0) {
-    sym = fq_base_code(r.b[0]);
-    unsigned c = 0;
-#pragma unroll
-    for (int k = 1; k <= 4; k++) {
-      const unsigned code = p >= (unsigned)k ? fq_base_code(r.b[k]) : ((0xD7u >> (2 * (4 + (int)p - k))) & 3u);
-      c |= code << (2 * (4 - k));
-    }
-    ctx = c;
+    const unsigned long long w = ((unsigned long long)r.hi << 32) | r.lo;
+    sym = code_lut[(unsigned)(w >> sh) & 0xFFu];
+    const unsigned prev = (unsigned)((unsigned long long)r.lo << (32u - sh));  // bytes p-1 | p-2 | p-3 | p-4
+    ctx = ((unsigned)code_lut[prev >> 24] << 6) | ((unsigned)code_lut[(prev >> 16) & 0xFFu] << 4) |
+          ((unsigned)code_lut[(prev >> 8) & 0xFFu] << 2) | (unsigned)code_lut[prev & 0xFFu] | (0xD7u >> (2u * pq));
   } else {
-    sym = r.b[0] - 33u;
-    const unsigned q = p >= 1 ? r.b[1] - 33u : 0u;
-    const unsigned q1 = p >= 2 ? r.b[2] - 33u : 0u;
-    const unsigned q2 = p >= 3 ? r.b[3] - 33u : 0u;
-    ctx = fq_qual_ctx(q & 63u, q1 & 63u, q2 & 63u);
+    (void)code_lut;
+    const unsigned w33 = r.lo - 0x21212121u;
+    sym = (w33 >> sh) & 0xFFu;
+    const unsigned prev = (unsigned)((unsigned long long)w33 << (32u - sh));  // q | q1 | q2 | -
+    ctx = fq_qual_ctx((prev >> 24) & 63u, (prev >> 16) & 63u, (prev >> 8) & 63u);
   }
-}
-
-template <class M>
-__device__ __forceinline__ void fq_sym_ctx(const uint8_t *__restrict__ raw, const fqgpu_rec &rec,
-                                           unsigned p, unsigned &ctx, unsigned &sym) {
-  const SymBytes r = fq_load_sym_bytes<M>(raw, rec, p, true);
-  fq_ctx_from_bytes<M>(r, p, ctx, sym);
 }
 
 #endif  // __HIPCC__
