@@ -99,6 +99,7 @@ _PROTOS = {
                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
     "fqgpu_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fqgpu_ctx_last_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    "fqgpu_ctx_timing_only": (C.c_int, [C.c_void_p, C.c_char_p]),
     "fqgpu_parse_fastq": (C.c_long, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "fqgpu_synth_fastq": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_uint64,
                                        C.POINTER(C.c_uint64)]),
@@ -310,7 +311,9 @@ class Context:
     def sync(self):
         _check(lib().fqgpu_sync(self.h), "sync")
 
-    def enable_timing(self, on=True):
+    def enable_timing(self, on=True, only=None):
+        """HIP-event spans around the kernel groups; only: restrict them to one group's label"""
+        _check(lib().fqgpu_ctx_timing_only(self.h, only.encode() if only else None), "timing_only")
         _check(lib().fqgpu_ctx_enable_timing(self.h, 1 if on else 0), "enable_timing")
 
     def last_timing(self):

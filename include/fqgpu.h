@@ -202,6 +202,10 @@ typedef struct {
 } fqgpu_timing;
 int fqgpu_ctx_enable_timing(fqgpu_ctx *ctx, int on);
 int fqgpu_ctx_last_timing(fqgpu_ctx *ctx, fqgpu_timing *out);
+/* Restricts the events to the kernel group of that name (NULL or "" = all groups again): two
+ * events per launch of that group instead of two per launch of every group -- the events between
+ * the kernels of a stream cost about 7 % of a step of 256 MiB blocks. */
+int fqgpu_ctx_timing_only(fqgpu_ctx *ctx, const char *name);
 
 /* ---- host helpers of the path's callers (not GPU code) ------------------
  * Minimal 4-line FASTQ parser with the reference's semantics
