@@ -156,20 +156,20 @@ def main():
         for b in dblocks:
             b.encode()
 
-    # Warm-up.  The last warm-up step runs with HIP events around EVERY kernel group: it gives the
+    # Warm-up, then ONE more untimed step with HIP events around EVERY kernel group: it gives the
     # table of all groups (kernels_ms) and names the dominant one.  The timed steps then carry events
-    # around that group only (two per launch on the stream it is launched on): events between all
-    # kernels of a stream cost about 7 % of the step.
+    # around that group only (two per launch, on the stream it is launched on): events between all
+    # kernels of a stream cost 2-3 % of the step.
     def spans_of():
         tot_ms, spans = ctx.last_timing()
         return {name: ms / max(n, 1) for name, ms, n in spans}, {name: n for name, ms, n in spans}
-    for i in range(args.warmup):
-        if i == args.warmup - 1:
-            ctx.sync()
-            ctx.enable_timing(True)
+    for _ in range(args.warmup):
         step()
     ctx.sync()
-    kern_all, _ = spans_of() if args.warmup else ({}, {})
+    ctx.enable_timing(True)
+    step()
+    ctx.sync()
+    kern_all, _ = spans_of()
     dom_name = max(kern_all.items(), key=lambda kv: kv[1])[0] if kern_all else None
     ctx.enable_timing(True, only=None if os.environ.get("FQ_BENCH_ALL_EVENTS") else dom_name)
     barrier()
@@ -242,7 +242,7 @@ def main():
                 "launches_timed": calls.get(dom[0], 0),
                 "job_GBps": round(alg_block * len(blocks) * args.steps / elapsed / 1e9, 2),
                 "job_frac": round(alg_block * len(blocks) * args.steps / elapsed / 1e9 / 8000.0, 5),
-                "kernels_ms_from": "last warm-up step (events around every kernel group); the roofline kernel: timed steps",
+                "kernels_ms_from": "one untimed step after the warm-up (events around every kernel group); the roofline kernel: the timed steps",
                 "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
 
     # ---- decode (after the timed region): same archive, then a many-small-blocks layout
