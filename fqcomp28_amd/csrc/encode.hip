@@ -169,7 +169,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                          sc.sorted_sym.as<uint8_t>(), lpos16, bd, fq_debug_no_sym(0));
   } else if (!dbg_off) {
     if (ctx->lds_atomics_ordered)
-      hipLaunchKernelGGL((k_scatter<M, true>), dim3(n_tiles), dim3(64), getenv("FQGPU_K3_LDS_PAD") ? atoi(getenv("FQGPU_K3_LDS_PAD")) : 0, st, ckey, csym, n_sym, T,
+      hipLaunchKernelGGL((k_scatter<M, true>), dim3(n_tiles), dim3(64), 0, st, ckey, csym, n_sym, T,
                          sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), sc.slot_of.as<uint32_t>(),
                          fq_debug_no_sym(M::STREAM));
     else
