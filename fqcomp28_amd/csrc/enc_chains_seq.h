@@ -63,13 +63,20 @@ constexpr unsigned SETS_MAX_CLASSES = 512;  // above this a segment keeps carryi
 constexpr unsigned SETS_MAX_GROUP = 16;     // segments a wave walks in one go, at most
 constexpr unsigned SETS_BLOCK = 1024;       // symbols per 16-byte-per-lane load; S is a multiple
 
-struct SetsWaveLds {
-  uint32_t bm[128];                  // bitmap over the states (size <= 4096)
-  uint16_t wpre[128];                // set bits before every bitmap word
-  uint16_t list[SETS_MAX_CLASSES];   // class -> state, as (state - size) * 2
-  uint16_t tmp[SETS_MAX_CLASSES];    // old class -> new class during a merge
-  uint16_t m[SETS_MAX_CLASSES];      // first-level class -> current class
+template <unsigned MAXC_, unsigned BMW_>
+struct SetsWaveLdsT {
+  static constexpr unsigned MAXC = MAXC_, BMW = BMW_;
+  uint32_t bm[BMW];       // bitmap over the states (size <= 32 * BMW)
+  uint16_t wpre[BMW];     // set bits before every bitmap word
+  uint16_t list[MAXC];    // class -> state, as (state - size) * 2
+  uint16_t tmp[MAXC];     // old class -> new class during a merge
+  uint16_t m[MAXC];       // first-level class -> current class
 };
+using SetsWaveLds = SetsWaveLdsT<SETS_MAX_CLASSES, 128>;    // any log <= 12
+// log <= 11 (the two-symbol kernel): 3456 B per wave, 16 waves + the 64 KB table = 118 KB, which
+// leaves 42 KB of a CU's LDS to the kernels of the other lanes -- the quality K1 and K3 need 36 KB
+// each and could not run beside a workgroup of this kernel while it took 125 KB
+using SetsWaveLds11 = SetsWaveLdsT<SETS_MAX_CLASSES, 64>;
 
 // Segments a k_seq_setfunc wave walks in one go ("group") for a chain with nf functions: as many
 // as keep >= gmin groups in the chain (a workgroup's waves all busy), at most qmax.
@@ -134,21 +141,30 @@ __device__ __forceinline__ unsigned sets_word(const uint4 cur, unsigned w) {
 }
 
 // number of distinct states marked in L.bm; fills L.wpre
-__device__ __forceinline__ unsigned sets_count(SetsWaveLds &L, unsigned nw) {
+template <class LT>
+__device__ __forceinline__ unsigned sets_count(LT &L, unsigned nw) {
   const unsigned lane = fq_lane();
-  const unsigned c0 = lane < nw ? __popc(L.bm[lane]) : 0u, c1 = lane + 64 < nw ? __popc(L.bm[lane + 64]) : 0u;
+  const unsigned c0 = lane < nw ? __popc(L.bm[lane]) : 0u;
   const unsigned p0 = sets_incl_scan(c0), t0 = __builtin_amdgcn_readlane(p0, 63);
-  const unsigned p1 = sets_incl_scan(c1), t1 = __builtin_amdgcn_readlane(p1, 63);
   L.wpre[lane] = (uint16_t)(p0 - c0);
-  L.wpre[lane + 64] = (uint16_t)(t0 + p1 - c1);
+  unsigned t1 = 0;
+  if (LT::BMW > 64) {
+    const unsigned c1 = lane + 64 < nw ? __popc(L.bm[lane + 64]) : 0u;
+    const unsigned p1 = sets_incl_scan(c1);
+    t1 = __builtin_amdgcn_readlane(p1, 63);
+    L.wpre[lane + 64] = (uint16_t)(t0 + p1 - c1);
+  }
   fq_lds_wave_sync();
   return t0 + t1;
 }
-__device__ __forceinline__ unsigned sets_rank(const SetsWaveLds &L, unsigned xi) {
+template <class LT>
+__device__ __forceinline__ unsigned sets_rank(const LT &L, unsigned xi) {
   return (unsigned)L.wpre[xi >> 5] + __popc(L.bm[xi >> 5] & ((1u << (xi & 31u)) - 1u));
 }
-__device__ __forceinline__ void sets_clear(SetsWaveLds &L) {
-  L.bm[fq_lane()] = 0; L.bm[fq_lane() + 64] = 0;
+template <class LT>
+__device__ __forceinline__ void sets_clear(LT &L) {
+  L.bm[fq_lane()] = 0;
+  if (LT::BMW > 64) L.bm[fq_lane() + 64] = 0;
   fq_lds_wave_sync();
 }
 
@@ -174,8 +190,8 @@ __device__ __forceinline__ uint4 sets_pack_rows(const uint4 cur, unsigned log) {
 }
 
 // n classes (states in L.list) walked through words [w0, w1) of the segment, M per lane
-template <int M, bool TWO>
-__device__ __forceinline__ void sets_walk(SetsWaveLds &L, unsigned n, const char *tbase, unsigned log,
+template <int M, bool TWO, class LT>
+__device__ __forceinline__ void sets_walk(LT &L, unsigned n, const char *tbase, unsigned log,
                                           const uint4 cur, const uint4 rows, unsigned w0, unsigned w1) {
   const unsigned lane = fq_lane();
   unsigned y[M];
@@ -229,8 +245,8 @@ __device__ __forceinline__ unsigned sets_idx(unsigned v, unsigned size) { return
 
 // merge of equal states among the n classes of L.list; returns the new class count.  Skipped
 // (list untouched) when it would not lower the number of gathers per step.
-template <bool XO>
-__device__ __forceinline__ unsigned sets_merge(SetsWaveLds &L, unsigned n, unsigned n1, unsigned nw, unsigned size) {
+template <bool XO, class LT>
+__device__ __forceinline__ unsigned sets_merge(LT &L, unsigned n, unsigned n1, unsigned nw, unsigned size) {
   const unsigned lane = fq_lane();
   sets_clear(L);
   for (unsigned i = lane; i < n; i += 64) {
@@ -240,16 +256,16 @@ __device__ __forceinline__ unsigned sets_merge(SetsWaveLds &L, unsigned n, unsig
   fq_lds_wave_sync();
   const unsigned nn = sets_count(L, nw);
   if ((nn + 63) / 64 >= (n + 63) / 64) return n;
-  unsigned st[SETS_MAX_CLASSES / 64];
+  unsigned st[LT::MAXC / 64];
 #pragma unroll
-  for (unsigned j = 0; j < SETS_MAX_CLASSES / 64; j++) {
+  for (unsigned j = 0; j < LT::MAXC / 64; j++) {
     const unsigned i = lane + 64u * j;
     st[j] = i < n ? (unsigned)L.list[i] : 0u;
     if (i < n) L.tmp[i] = (uint16_t)sets_rank(L, sets_idx<XO>(st[j], size));
   }
   fq_lds_wave_sync();
 #pragma unroll
-  for (unsigned j = 0; j < SETS_MAX_CLASSES / 64; j++) {
+  for (unsigned j = 0; j < LT::MAXC / 64; j++) {
     const unsigned i = lane + 64u * j;
     if (i < n) L.list[L.tmp[i]] = (uint16_t)st[j];  // equal states write the same value
   }
@@ -260,20 +276,26 @@ __device__ __forceinline__ unsigned sets_merge(SetsWaveLds &L, unsigned n, unsig
 
 // Step A.  PER0 = states per lane at the start: 32 covers log <= 11, 64 covers log 12.
 // TWO: two symbols per gather through the context's 64 KB two-symbol table (log <= 11).
+// Registers: the two-symbol kernel is held to 96 VGPRs (five waves per SIMD; it spills 8 more
+// registers of its rarely run merge code than at 128).  A workgroup is 4 waves per SIMD: at 128
+// VGPRs they filled the SIMD's register file and NOTHING else could run on a CU while this
+// kernel held it -- its time simply added to the step.  With 96, waves of the other lanes'
+// kernels fit beside it: 66.9 -> 70.8 GB/s (80 VGPRs: 68.8; 64: 65.7).
 template <unsigned PER0, bool TWO>
-__global__ void __launch_bounds__((TWO ? SETS_WAVES2 : SETS_WAVES) * 64)
+__global__ void __launch_bounds__((TWO ? SETS_WAVES2 : SETS_WAVES) * 64, TWO ? 5 : 1)
 k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
               const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs,
               const uint16_t *__restrict__ next, unsigned next_stride, unsigned S, unsigned qmax, unsigned gmin,
               unsigned rounds, unsigned fstride, uint16_t *__restrict__ fbuf, unsigned *__restrict__ work_counter) {
   constexpr unsigned WAVES = TWO ? SETS_WAVES2 : SETS_WAVES;
   extern __shared__ uint32_t lds[];  // next[4][size] (TWO: next2[16][size]) of this context
-  __shared__ SetsWaveLds wl[WAVES];
+  using LT = typename std::conditional<TWO, SetsWaveLds11, SetsWaveLds>::type;
+  __shared__ LT wl[WAVES];
   __shared__ unsigned s_next, s_item;
   constexpr unsigned B = SeqModel::B;
   const uint32_t *fitem = plan, *fseg = plan + (B + 1);
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
-  SetsWaveLds &L = wl[wave];
+  LT &L = wl[wave];
   const char *tbase = reinterpret_cast<const char *>(lds);
   const unsigned sub_blocks = S / SETS_BLOCK;  // 1024-symbol loads per segment
   const unsigned n_items = fitem[B];

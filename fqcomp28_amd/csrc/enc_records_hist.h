@@ -178,7 +178,7 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
         bad |= sym >= (unsigned)M::A;
         if (!(dbg & 2)) {
           if (M::STREAM == 0) ckey[e] = (uint16_t)(ctx | ((sym & 3u) << 8));
-          else { ckey[e] = (uint16_t)ctx; csym[e] = (uint8_t)(sym & 63u); }
+          else { if (!(dbg & 8)) ckey[e] = (uint16_t)ctx; if (!(dbg & 4)) csym[e] = (uint8_t)(sym & 63u); }
         }
         if (!(dbg & 1)) atomicAdd(&hist[ctx], 1u);
       }

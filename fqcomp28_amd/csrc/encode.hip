@@ -135,6 +135,11 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   uint16_t *ckey = sc.keys.as<uint16_t>();
   uint8_t *csym = reinterpret_cast<uint8_t *>(ckey + n_pad);
   uint16_t *enc16 = ckey;  // the keys are dead after K3
+  static const bool dbg_no_alias = getenv("FQGPU_DEBUG_NO_ALIAS") != nullptr;  // timing experiments that skip K1 or its stores
+  if (dbg_no_alias) {
+    if ((rc = sc.dbg_enc16.reserve(n_pad * 2))) return rc;
+    enc16 = sc.dbg_enc16.as<uint16_t>();
+  }
   uint32_t *arrays = sc.ctx_arrays.as<uint32_t>();
   uint16_t *final_state = sc.seg_state.as<uint16_t>();
   const unsigned lds_ct = (1u + (1u << (tab.max_log - 1)) + 2u * M::A) * 4u;

@@ -110,6 +110,7 @@ struct EncScratch {
   DevBuf seq_fbuf;    // u16 [segments][1 << max_log] segment functions F: entry state -> exit state
   DevBuf tile_bits;   // u32 [ptiles]
   DevBuf tile_bit_base;  // u64 [ptiles+1]
+  DevBuf dbg_enc16;   // timing experiments only (FQGPU_DEBUG_NO_ALIAS): enc16 apart from the keys, so that stale keys stay valid
   DevBuf scan_tmp;    // u64 chunk sums for the scans
 };
 
