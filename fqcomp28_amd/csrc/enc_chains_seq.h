@@ -300,7 +300,7 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
   const unsigned sub_blocks = S / SETS_BLOCK;  // 1024-symbol loads per segment
   const unsigned n_items = fitem[B];
   unsigned loaded = 0xFFFFFFFFu;  // context whose table is in LDS
-  // Persistent workgroups (one per CU, 125 KB of LDS with the two-symbol table): items are
+  // Persistent workgroups (one per CU, 118 KB of LDS with the two-symbol table): items are
   // (context, group of WAVES * SETS_ROUNDS segments), taken from a global counter, so a
   // workgroup that has found a CU keeps it until the work is gone.
   for (;;) {
