@@ -1,10 +1,15 @@
-"""Timing experiment (wrong output by design): how much of the step is the scattered byte stores of
-the partition kernels?  Runs the configs[1] encode step normally, then again with
-FQGPU_DEBUG_NO_SYM_STORE set (sorted_sym keeps the bytes of the previous step)."""
+"""Timing experiment (wrong output by design): marginal cost of kernel groups / classes of stores.
+Runs the configs[1] encode step normally, then again with every NAME[=VALUE] given on the command
+line set in the environment (FQGPU_DEBUG_SKIP=<mask>, FQGPU_DEBUG_K1=<bits>, FQGPU_DEBUG_NO_SYM_STORE=1
+...): what is not launched or stored keeps the previous step's data.
+FQGPU_DEBUG_NO_ALIAS=1 is set here: enc16 normally lives in the key buffer, so without it a step
+that skips K1 (or its key stores) would partition the previous step's (nb, bits) as if they were
+keys and everything behind K1 would run on garbage -- that made "K1's key stores" look like 3 ms."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("FQGPU_DEBUG_NO_ALIAS", "1")
 import fqcomp28_amd as F
 import bench
 
