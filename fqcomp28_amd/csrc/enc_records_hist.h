@@ -135,14 +135,23 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
             const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
             uint32_t *__restrict__ tile_hist, uint16_t *__restrict__ ckey, uint8_t *__restrict__ csym,
             StreamResult *res, int dbg) {
-  __shared__ uint32_t hist[M::B];
+  // Quality stream: 16-bit counters, two per word -- 16 KB of LDS instead of 32, so that a CU takes
+  // seven of these workgroups, or four and still has room for another kernel's.  A tile has up to
+  // 65536 symbols: a counter overflows only if ALL of them share one context (constant Phred 0:
+  // every context is calcContext(0, 0, 0)); then the counter of the tile's first symbol reads 0,
+  // which no other tile can produce, and the histogram is rebuilt from that (see the write-out).
+  constexpr bool PACKED = M::B > 1024;
+  constexpr unsigned HWORDS = PACKED ? M::B / 2 : M::B;
+  __shared__ uint32_t hist[HWORDS];
+  __shared__ unsigned s_first_ctx;
   __shared__ RecCache rcache[4];  // one per wave
   __shared__ uint8_t code_lut[256];  // fq_base_code of every byte value (sequence stream)
   code_lut[threadIdx.x & 255u] = (uint8_t)fq_base_code(threadIdx.x & 255u);
   const unsigned tile = blockIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
-  for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x) hist[c] = 0;
+  for (unsigned c = threadIdx.x; c < HWORDS; c += blockDim.x) hist[c] = 0;
+  if (threadIdx.x == 0) s_first_ctx = 0;
   __syncthreads();
   // every wave takes a contiguous share of the tile (multiple of 64 symbols)
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
@@ -180,7 +189,14 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
           if (M::STREAM == 0) ckey[e] = (uint16_t)(ctx | ((sym & 3u) << 8));
           else { if (!(dbg & 8)) ckey[e] = (uint16_t)ctx; if (!(dbg & 4)) csym[e] = (uint8_t)(sym & 63u); }
         }
-        if (!(dbg & 1)) atomicAdd(&hist[ctx], 1u);
+        if (!(dbg & 1)) {
+          if (PACKED) {
+            atomicAdd(&hist[ctx >> 1], 1u << (16u * (ctx & 1u)));
+            if (e == e0) s_first_ctx = ctx;
+          } else {
+            atomicAdd(&hist[ctx], 1u);
+          }
+        }
       }
     };
     for (unsigned eb = wb; eb < we;) {
@@ -215,8 +231,15 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   if (bad) atomicOr(&res->bad_symbol, 1u);
   __syncthreads();
   if (dbg & 1) return;  // timing experiment: the previous encode's histogram stays
-  for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x)
-    tile_hist[(size_t)tile * M::B + c] = hist[c];
+  if (PACKED) {
+    const unsigned c0 = s_first_ctx;
+    const bool wrapped = e1 > e0 && ((hist[c0 >> 1] >> (16u * (c0 & 1u))) & 0xFFFFu) == 0u;  // 65536 symbols, all in c0
+    for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x)
+      tile_hist[(size_t)tile * M::B + c] = wrapped ? (c == c0 ? e1 - e0 : 0u) : (hist[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu;
+  } else {
+    for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x)
+      tile_hist[(size_t)tile * M::B + c] = hist[c];
+  }
 }
 
 // ------------------------------------------------------------------ K2: layout of the sorted arrays

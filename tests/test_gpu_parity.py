@@ -444,6 +444,25 @@ def test_sequence_segment_functions_are_exact(F, bases, segment):
     ctx.close()
 
 
+def test_constant_phred0_qualities_fill_whole_tiles_with_one_context(F):
+    """All qualities '!' (Phred 0): calcContext(0, 0, 0) for EVERY position, the read starts
+    included, so whole 65536-symbol tiles hold one context -- the one input on which K1's 16-bit
+    tile counters (two per word) overflow and the histogram is rebuilt from the first symbol's
+    context, and on which K3's 16-bit cursor reaches 65536 with the last symbol of a tile."""
+    raw, recs = _synth(F, 2, 6 << 20)
+    raw = raw.copy()
+    for r in recs:
+        raw[r["qual_off"]: r["qual_off"] + r["len"]] = ord("!")
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    g = ctx.encode_block(raw, recs)
+    assert_same_encoding(g, e)
+    rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
 @pytest.mark.parametrize("segment", [1024, 4096])
 @pytest.mark.parametrize("quals", ["binned", "two_levels_rare_third"])
 def test_quality_tables_without_reset_symbols(F, quals, segment):
