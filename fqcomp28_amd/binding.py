@@ -7,7 +7,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libfqgpu.so")
+# FQGPU_LIB: another build of the same ABI (tools/traffic_experiment.py loads the -DFQGPU_EXPERIMENTS one)
+LIB_PATH = os.environ.get("FQGPU_LIB") or os.path.join(HERE, "libfqgpu.so")
 
 SEQ_MODELS, SEQ_ALPHA = 256, 4
 QUAL_MODELS, QUAL_ALPHA = 8192, 64

@@ -12,9 +12,15 @@
 // The encode lanes use up to 16 streams (two per block in flight: sequence and quality pipelines).  ROCm maps streams onto
 // GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
 // run back to back; ask for 16 before the runtime initialises (one per stream of 8 lanes;
-// 24 helps blocks of 16 MiB and less by a fifth and costs 256 MiB blocks 2 %) (no effect if the host
-// application already initialised HIP or set the variable itself).
-__attribute__((constructor)) static void fq_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// 24 helps blocks of 16 MiB and less by a fifth and costs 256 MiB blocks 2 %).  This touches the
+// host process's environment, so it is narrow and can be switched off: it never overrides a value
+// the application (or the user) set, it has no effect once HIP is initialised, and
+// FQGPU_KEEP_HW_QUEUES=1 in the environment makes the library leave the variable alone
+// ("Environment").
+__attribute__((constructor)) static void fq_ask_for_hw_queues() {
+  if (getenv("FQGPU_KEEP_HW_QUEUES")) return;
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_hip_msg[256] = "";
@@ -291,7 +297,7 @@ extern "C" int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len,
         hipMemset(cnt + ns + nq, 0, 4) != hipSuccess) { rc = FQGPU_E_HIP; break; }
     if ((rc = fq_build_freq_tables(device, st, raw_dev, recs_dev, n_recs, cnt, cnt + ns))) break;
     if (hipMemcpy(&err, cnt + ns + nq, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = FQGPU_E_HIP; break; }
-    if (err) { rc = FQGPU_E_ARG; break; }  // quality above Q63: the reference throws (src/fse_quality.cpp:88)
+    if (err) { rc = FQGPU_E_ARG; break; }  // quality above Q63: the reference throws (src/fse_quality.cpp:88); a base byte outside ACGTN
     if (seq_counts_out && hipMemcpy(seq_counts_out, cnt, ns * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = FQGPU_E_HIP; break; }
     if (qual_counts_out && hipMemcpy(qual_counts_out, cnt + ns, nq * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = FQGPU_E_HIP; break; }
     if ((rc = normalize_to_host(st, cnt, 0, seq_ft_out))) break;
@@ -498,8 +504,10 @@ extern "C" void fqgpu_dblock_destroy(fqgpu_dblock *b) {
 static int alloc_block_outputs(fqgpu_dblock *b) {
   b->seq_cap = fqgpu_bound_seq(b->n_bases);
   b->qual_cap = fqgpu_bound_qual(b->n_bases);
-  b->seq = fq_dev_alloc<uint8_t>(b->seq_cap + 64);
-  b->qual = fq_dev_alloc<uint8_t>(b->qual_cap + 64);
+  b->seq_alloc = b->seq_cap + 64;
+  b->qual_alloc = b->qual_cap + 64;
+  b->seq = fq_dev_alloc<uint8_t>(b->seq_alloc);
+  b->qual = fq_dev_alloc<uint8_t>(b->qual_alloc);
   b->readlens = fq_dev_alloc<uint16_t>(b->n_recs);
   b->n_count = fq_dev_alloc<uint16_t>(b->n_recs);
   b->n_pos = fq_dev_alloc<uint16_t>(b->n_pos_cap + 16);
@@ -526,6 +534,7 @@ extern "C" int fqgpu_dblock_create(fqgpu_ctx *ctx, const uint8_t *raw, size_t ra
   fqgpu_dblock *b = new (std::nothrow) fqgpu_dblock();
   if (!b) return FQGPU_E_NOMEM;
   b->device = ctx->device;
+  b->owner = ctx;
   b->raw_len = raw_len; b->n_recs = n_recs; b->n_bases = n_bases;
   b->n_pos_cap = n_n;
   b->raw = fq_dev_alloc<uint8_t>(raw_len + 64);
@@ -556,6 +565,7 @@ extern "C" int fqgpu_dblock_create_from_raw(fqgpu_ctx *ctx, const uint8_t *raw, 
   fqgpu_dblock *b = new (std::nothrow) fqgpu_dblock();
   if (!b) return FQGPU_E_NOMEM;
   b->device = ctx->device;
+  b->owner = ctx;
   b->raw = fq_dev_alloc<uint8_t>(raw_len + 64);
   if (!b->raw) { fqgpu_dblock_destroy(b); return FQGPU_E_NOMEM; }
   hipError_t he = hipMemsetAsync(b->raw + raw_len, 0, 64, ctx->stream);
@@ -597,6 +607,7 @@ extern "C" int fqgpu_dblock_encode(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned fla
   int rc = use_device(ctx->device);
   if (rc) return rc;
   b->last_op = 1;
+  b->result_pulled = false;
   return fq_encode_launch(ctx, b, flags);
 }
 
@@ -623,6 +634,7 @@ extern "C" int fqgpu_sync(fqgpu_ctx *ctx) {
 // stream sizes a later decode of this block uses.
 static int pull_result(fqgpu_dblock *b, bool from_encode) {
   FQ_HIP(hipMemcpy(&b->host_result, b->result, sizeof(BlockResult), hipMemcpyDeviceToHost));
+  b->result_pulled = true;
   const BlockResult &r = b->host_result;
   if (r.s[1].bad_symbol || r.s[0].bad_symbol) return FQGPU_E_ARG;
   if (from_encode) {
@@ -641,7 +653,11 @@ extern "C" int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_
   if (!b) return FQGPU_E_ARG;
   fqgpu_dblock *mb = const_cast<fqgpu_dblock *>(b);
   (void)hipSetDevice(b->device);
-  int rc = b->last_op ? pull_result(mb, b->last_op == 1) : FQGPU_OK;
+  // The lanes run on non-blocking streams: a copy on the null stream is not ordered behind them.
+  // An operation still in flight is waited for here (its sizes would otherwise read zero or stale).
+  int rc = FQGPU_OK;
+  if (b->last_op && !b->result_pulled && b->owner && (rc = fqgpu_sync(b->owner))) return rc;
+  rc = b->last_op ? pull_result(mb, b->last_op == 1) : FQGPU_OK;
   if (seq_len) *seq_len = b->seq_len;
   if (qual_len) *qual_len = b->qual_len;
   if (n_pos_len) *n_pos_len = b->n_pos_len;
@@ -665,6 +681,8 @@ extern "C" int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t
   if (!ctx || !b) return FQGPU_E_ARG;
   int rc = fqgpu_sync(ctx);
   if (rc) return rc;
+  // sizes of an encode nobody has asked the status of yet
+  if (b->last_op && !b->result_pulled && (rc = pull_result(const_cast<fqgpu_dblock *>(b), b->last_op == 1))) return rc;
   if (seq_out && b->seq_len) FQ_HIP(hipMemcpy(seq_out, b->seq, b->seq_len, hipMemcpyDeviceToHost));
   if (qual_out && b->qual_len) FQ_HIP(hipMemcpy(qual_out, b->qual, b->qual_len, hipMemcpyDeviceToHost));
   if (readlens_out) FQ_HIP(hipMemcpy(readlens_out, b->readlens, b->n_recs * 2, hipMemcpyDeviceToHost));
@@ -681,15 +699,16 @@ extern "C" int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const 
   int rc = fqgpu_sync(ctx);
   if (rc) return rc;
   // foreign streams may be larger than what this block's own encode would need
-  if (seq_len + 64 > b->seq_cap + 64) {
+  // (seq_cap / qual_cap stay the capacities a later re-encode of this block is judged against)
+  if (seq_len + 64 > b->seq_alloc) {
     (void)hipFree(b->seq);
     b->seq = fq_dev_alloc<uint8_t>(seq_len + 64);
-    b->seq_cap = seq_len;
+    b->seq_alloc = b->seq ? seq_len + 64 : 0;
   }
-  if (qual_len + 64 > b->qual_cap + 64) {
+  if (qual_len + 64 > b->qual_alloc) {
     (void)hipFree(b->qual);
     b->qual = fq_dev_alloc<uint8_t>(qual_len + 64);
-    b->qual_cap = qual_len;
+    b->qual_alloc = b->qual ? qual_len + 64 : 0;
   }
   if (n_pos_len > b->n_pos_cap) {
     (void)hipFree(b->n_pos);
@@ -704,6 +723,8 @@ extern "C" int fqgpu_dblock_load_streams(fqgpu_ctx *ctx, fqgpu_dblock *b, const 
   FQ_HIP(hipMemcpy(b->n_count, n_count, b->n_recs * 2, hipMemcpyHostToDevice));
   if (n_pos_len) FQ_HIP(hipMemcpy(b->n_pos, n_pos, n_pos_len * 2, hipMemcpyHostToDevice));
   b->seq_len = seq_len; b->qual_len = qual_len; b->n_pos_len = n_pos_len;
+  b->last_op = 0;  // the result block no longer describes these streams
+  b->result_pulled = true;
   b->index_bytes[0] = b->index_bytes[1] = 0;  // an index belongs to the streams it was made for
   return FQGPU_OK;
 }
@@ -713,9 +734,19 @@ extern "C" int fqgpu_dblocks_decode(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks,
   int rc = use_device(ctx->device);
   if (rc) return rc;
   for (size_t i = 0; i < n_blocks; i++)
-    if (!blocks[i] || blocks[i]->device != ctx->device || !blocks[i]->seq_len || !blocks[i]->qual_len)
-      return FQGPU_E_ARG;
-  for (size_t i = 0; i < n_blocks; i++) blocks[i]->last_op = 2;
+    if (!blocks[i] || blocks[i]->device != ctx->device) return FQGPU_E_ARG;
+  // blocks that come straight out of an encode: wait for it and take over its stream sizes
+  bool synced = false;
+  for (size_t i = 0; i < n_blocks; i++) {
+    fqgpu_dblock *b = blocks[i];
+    if (b->last_op == 1 && !b->result_pulled) {
+      if (!synced && (rc = fqgpu_sync(ctx))) return rc;
+      synced = true;
+      if ((rc = pull_result(b, true))) return rc;
+    }
+    if (!b->seq_len || !b->qual_len) return FQGPU_E_ARG;
+  }
+  for (size_t i = 0; i < n_blocks; i++) { blocks[i]->last_op = 2; blocks[i]->result_pulled = false; }
   return fq_decode_launch(ctx, blocks, n_blocks);
 }
 
@@ -737,11 +768,13 @@ static int hp_block_acquire(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_
                             size_t qual_cap, size_t n_pos_cap, fqgpu_dblock **out) {
   fqgpu_dblock *b = ctx->hp_block;
   if (!b) {
-    b = ctx->hp_block = new (std::nothrow) fqgpu_dblock();
+    b = new (std::nothrow) fqgpu_dblock();
     if (!b) return FQGPU_E_NOMEM;
     b->device = ctx->device;
+    b->owner = ctx;
     b->result = fq_dev_alloc<BlockResult>(1);
-    if (!b->result) return FQGPU_E_NOMEM;
+    if (!b->result) { delete b; return FQGPU_E_NOMEM; }  // published only when complete
+    ctx->hp_block = b;
   }
   size_t side2 = ctx->hp_side;
   const bool ok = hp_grow(b->raw, ctx->hp_raw, raw_len + 64) && hp_grow(b->recs, ctx->hp_recs, n_recs) &&
@@ -756,9 +789,11 @@ static int hp_block_acquire(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_
   }
   b->raw_len = raw_len; b->n_recs = n_recs; b->n_bases = n_bases;
   b->seq_cap = seq_cap; b->qual_cap = qual_cap; b->n_pos_cap = n_pos_cap;
+  b->seq_alloc = ctx->hp_seq; b->qual_alloc = ctx->hp_qual;
   b->seq_len = b->qual_len = b->n_pos_len = 0;
   b->index_bytes[0] = b->index_bytes[1] = 0;
   b->last_op = 0;
+  b->result_pulled = true;
   memset(&b->host_result, 0, sizeof(b->host_result));
   *out = b;
   return FQGPU_OK;

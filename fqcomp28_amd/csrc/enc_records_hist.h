@@ -145,8 +145,9 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   __shared__ uint32_t hist[HWORDS];
   __shared__ unsigned s_first_ctx;
   __shared__ RecCache rcache[4];  // one per wave
-  __shared__ uint8_t code_lut[256];  // fq_base_code of every byte value (sequence stream)
+  __shared__ uint8_t code_lut[256], sym_lut[256];  // fq_base_code / fq_base_sym of every byte value (sequence stream)
   code_lut[threadIdx.x & 255u] = (uint8_t)fq_base_code(threadIdx.x & 255u);
+  sym_lut[threadIdx.x & 255u] = (uint8_t)fq_base_sym(threadIdx.x & 255u);
   const unsigned tile = blockIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
@@ -183,7 +184,7 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
       const unsigned e = eb2 + lane;
       if (e < lim) {
         unsigned ctx, sym;
-        fq_ctx_from_bytes<M>(buf[slot], bp[slot], ctx, sym, code_lut);
+        fq_ctx_from_bytes<M>(buf[slot], bp[slot], ctx, sym, code_lut, sym_lut);
         bad |= sym >= (unsigned)M::A;
         if (!(dbg & 2)) {
           if (M::STREAM == 0) ckey[e] = (uint16_t)(ctx | ((sym & 3u) << 8));

@@ -59,9 +59,12 @@ template <class M> constexpr unsigned tile_size() { return M::STREAM == 0 ? TILE
 #define FQ_SPAN_BEGIN(name) fq_timer_span_begin(ctx, name, st)
 #define FQ_SPAN_END() fq_timer_span_end(ctx, st)
 
-// timing experiments only (tools/traffic_experiment.py): FQGPU_DEBUG_SKIP = bit mask of kernel groups
-// that are NOT launched; their outputs keep the values of the previous encode of the same lane
-// FQGPU_DEBUG_NO_SYM_STORE: 1 = both streams, 2 = sequence only, 3 = quality only
+// Timing experiments (tools/traffic_experiment.py) exist only in a library built with
+// -DFQGPU_EXPERIMENTS (make experiments -> tools/_build/libfqgpu_experiments.so); the product
+// library contains none of these switches.  FQGPU_DEBUG_SKIP = bit mask of kernel groups that are
+// NOT launched (their outputs keep the values of the previous encode of the same lane: wrong output
+// by design); FQGPU_DEBUG_NO_SYM_STORE: 1 = both streams, 2 = sequence only, 3 = quality only.
+#ifdef FQGPU_EXPERIMENTS
 static int fq_debug_no_sym(int stream) {
   const char *e = getenv("FQGPU_DEBUG_NO_SYM_STORE");
   const int v = e ? atoi(e) : 0;
@@ -71,6 +74,14 @@ static unsigned fq_debug_skip() {
   const char *e = getenv("FQGPU_DEBUG_SKIP");
   return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
 }
+static int fq_debug_k1() { const char *e = getenv("FQGPU_DEBUG_K1"); return e ? atoi(e) : 0; }
+static bool fq_debug_flag(const char *name) { return getenv(name) != nullptr; }
+#else
+static constexpr int fq_debug_no_sym(int) { return 0; }
+static constexpr unsigned fq_debug_skip() { return 0u; }
+static constexpr int fq_debug_k1() { return 0; }
+static constexpr bool fq_debug_flag(const char *) { return false; }
+#endif
 
 template <class M>
 int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b,
@@ -135,7 +146,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   uint16_t *ckey = sc.keys.as<uint16_t>();
   uint8_t *csym = reinterpret_cast<uint8_t *>(ckey + n_pad);
   uint16_t *enc16 = ckey;  // the keys are dead after K3
-  static const bool dbg_no_alias = getenv("FQGPU_DEBUG_NO_ALIAS") != nullptr;  // timing experiments that skip K1 or its stores
+  static const bool dbg_no_alias = fq_debug_flag("FQGPU_DEBUG_NO_ALIAS");  // timing experiments that skip K1 or its stores
   if (dbg_no_alias) {
     if ((rc = sc.dbg_enc16.reserve(n_pad * 2))) return rc;
     enc16 = sc.dbg_enc16.as<uint16_t>();
@@ -149,7 +160,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");  dbg_off = (dbg_mask & 1u) != 0;
   if (!dbg_off) hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs,
                      rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), ckey, csym, res,
-                     getenv("FQGPU_DEBUG_K1") ? atoi(getenv("FQGPU_DEBUG_K1")) : 0);
+                     fq_debug_k1());
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");  dbg_off = (dbg_mask & 2u) != 0;
   if (!dbg_off) hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
@@ -194,7 +205,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     const unsigned Q = min(max(ctx->seq_group, 1u), SETS_MAX_GROUP), gmin = max(ctx->seq_group_min, 1u);
     const unsigned rounds = max(SETS_ROUNDS / Q, 1u);
     const unsigned max_fitems = seq_max_segs / (wpg * rounds) + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
-    static const bool dbg_skip = getenv("FQGPU_DEBUG_SKIP_SEQ_CHAIN") != nullptr;  // timing experiment only: wrong output
+    static const bool dbg_skip = fq_debug_flag("FQGPU_DEBUG_SKIP_SEQ_CHAIN");  // timing experiment only: wrong output
     if (!dbg_off) hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, Q, gmin, wpg * rounds, plan);
     FQ_SPAN_END();
     FQ_SPAN_BEGIN("seq.setfunc");
@@ -399,7 +410,7 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
   FQ_HIP(hipEventRecord(lane.ev_fork, lane.st_seq));
   FQ_HIP(hipStreamWaitEvent(lane.st_qual, lane.ev_fork, 0));
   // timing experiments only (wrong output): one stream at a time
-  static const bool dbg_no_qual = getenv("FQGPU_DEBUG_SKIP_QUAL") != nullptr, dbg_no_seq = getenv("FQGPU_DEBUG_SKIP_SEQ") != nullptr;
+  static const bool dbg_no_qual = fq_debug_flag("FQGPU_DEBUG_SKIP_QUAL"), dbg_no_seq = fq_debug_flag("FQGPU_DEBUG_SKIP_SEQ");
   if (!dbg_no_qual && (rc = encode_stream<QualModel>(ctx, lane, lane.st_qual, b, rec_start, b->qual, b->qual_cap, flags))) return rc;
   if (!dbg_no_seq && (rc = encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, b->seq, b->seq_cap, flags))) return rc;
   FQ_HIP(hipEventRecord(lane.ev_join, lane.st_qual));

@@ -156,19 +156,22 @@ EncLane *fq_next_lane(fqgpu_ctx *ctx);  // api.hip: round-robin, creates streams
 
 struct fqgpu_dblock {
   int device = 0;
+  fqgpu_ctx *owner = nullptr;  // the handle whose lanes code this block (status / fetch synchronise it)
   uint8_t *raw = nullptr;
   size_t raw_len = 0;
   fqgpu_rec *recs = nullptr;
   size_t n_recs = 0;
   size_t n_bases = 0;
-  uint8_t *seq = nullptr;  size_t seq_cap = 0;
+  uint8_t *seq = nullptr;  size_t seq_cap = 0;   // capacities the overflow rule is judged against (reference rule or the caller's)
   uint8_t *qual = nullptr; size_t qual_cap = 0;
+  size_t seq_alloc = 0, qual_alloc = 0;          // bytes allocated behind seq / qual (>= cap + 64)
   uint16_t *readlens = nullptr, *n_count = nullptr, *n_pos = nullptr;
   size_t n_pos_cap = 0;
   BlockResult *result = nullptr;  // device
   BlockResult host_result;        // filled by fqgpu_sync-ing calls
   size_t seq_len = 0, qual_len = 0, n_pos_len = 0;  // stream sizes used by decode
   int last_op = 0;  // 1 = encode, 2 = decode: which fields of the result block are meaningful
+  bool result_pulled = true;  // host_result / stream sizes reflect the last launched operation
   // decode index (extension): device copy per stream, valid bytes, allocated bytes
   uint8_t *index[2] = {nullptr, nullptr};
   size_t index_bytes[2] = {0, 0}, index_cap[2] = {0, 0};
@@ -271,6 +274,13 @@ __device__ __forceinline__ unsigned long long fq_match_any(unsigned key, bool va
 __device__ __forceinline__ unsigned fq_base_code(unsigned c) {
   return (c == 'C' ? 1u : 0u) | (c == 'G' ? 2u : 0u) | (c == 'T' ? 3u : 0u);
 }
+// The reference's base2bits_arr (src/fse_sequence.cpp:6-14) maps everything but A, C, G, T to
+// UINT_MAX -- lowercase, IUPAC codes, '.', a stray '\r' index out of its tables (assert / UB); N is
+// legal because replaceAndEncodeNs (:35-51) has turned it into 'A' before.  A lossless coder must
+// not code such a byte as 'A' silently: symbol code as above, 4 for a byte that is not a base.
+__device__ __forceinline__ unsigned fq_base_sym(unsigned c) {
+  return (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') ? fq_base_code(c) : 4u;
+}
 
 // FSE_Quality::calcContext (src/fse_quality.h:40-44)
 __device__ __forceinline__ unsigned fq_qual_ctx(unsigned q, unsigned q1, unsigned q2) {
@@ -334,19 +344,21 @@ __device__ __forceinline__ SymBytes fq_load_sym_bytes(const uint8_t *__restrict_
 //            virtual bases in front of the read are 0xD7 >> 2 p (src/fse_sequence.h:22-24 applied p times)
 //  quality:  33 is subtracted from all four bytes at once (a byte < 33 borrows from its upper
 //            neighbour, but then the block is refused anyway: that byte is somebody's symbol >= 64)
+//            The SYMBOL goes through a second table (sym_lut = fq_base_sym): 4 for a byte that is
+//            no base at all, which the caller turns into FQGPU_E_ARG -- same instruction count.
 template <class M>
 __device__ __forceinline__ void fq_ctx_from_bytes(const SymBytes &r, unsigned p, unsigned &ctx, unsigned &sym,
-                                                  const uint8_t *code_lut) {
+                                                  const uint8_t *code_lut, const uint8_t *sym_lut) {
   constexpr unsigned K = M::STREAM == 0 ? 4u : 3u;
   const unsigned pq = min(p, K), sh = 8u * pq;  // the symbol is byte pq of the window
   if (M::STREAM == 0) {
     const unsigned long long w = ((unsigned long long)r.hi << 32) | r.lo;
-    sym = code_lut[(unsigned)(w >> sh) & 0xFFu];
+    sym = sym_lut[(unsigned)(w >> sh) & 0xFFu];
     const unsigned prev = (unsigned)((unsigned long long)r.lo << (32u - sh));  // bytes p-1 | p-2 | p-3 | p-4
     ctx = ((unsigned)code_lut[prev >> 24] << 6) | ((unsigned)code_lut[(prev >> 16) & 0xFFu] << 4) |
           ((unsigned)code_lut[(prev >> 8) & 0xFFu] << 2) | (unsigned)code_lut[prev & 0xFFu] | (0xD7u >> (2u * pq));
   } else {
-    (void)code_lut;
+    (void)code_lut; (void)sym_lut;
     const unsigned w33 = r.lo - 0x21212121u;
     sym = (w33 >> sh) & 0xFFu;
     const unsigned prev = (unsigned)((unsigned long long)w33 << (32u - sh));  // q | q1 | q2 | -

@@ -19,12 +19,13 @@ namespace {
 // (src/fse_sequence.cpp:156-158): the context of a base is the last four non-N bases.
 __global__ void __launch_bounds__(256)
 k_hist_seq(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R,
-           uint32_t *__restrict__ counts) {
+           uint32_t *__restrict__ counts, uint32_t *__restrict__ err) {
   __shared__ uint32_t hist[FQGPU_SEQ_MODELS * FQGPU_SEQ_ALPHA];
   for (unsigned i = threadIdx.x; i < FQGPU_SEQ_MODELS * FQGPU_SEQ_ALPHA; i += blockDim.x) hist[i] = 0;
   __syncthreads();
   const unsigned waves = (gridDim.x * blockDim.x) >> 6;
   const unsigned lane = fq_lane();
+  bool bad = false;  // a byte that is neither a base nor N (base2bits_arr: UINT_MAX, src/fse_sequence.cpp:6-14)
   for (unsigned r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < R; r += waves) {
     const fqgpu_rec rec = recs[r];
     const uint8_t *s = raw + rec.seq_off;
@@ -34,6 +35,7 @@ k_hist_seq(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, 
       const unsigned ch = i < rec.len ? s[i] : 'N';
       const bool keep = i < rec.len && ch != 'N';
       const unsigned code = fq_base_code(ch);
+      bad |= fq_base_sym(ch) > 3u;
       const unsigned long long km = __ballot(keep);
       unsigned long long m = km & ((1ull << lane) - 1ull);  // kept lanes before me
       const unsigned avail = (unsigned)__popcll(m);
@@ -59,6 +61,7 @@ k_hist_seq(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, 
       }
     }
   }
+  if (bad) atomicOr(err, 1u);
   __syncthreads();
   for (unsigned i = threadIdx.x; i < FQGPU_SEQ_MODELS * FQGPU_SEQ_ALPHA; i += blockDim.x)
     if (hist[i]) atomicAdd(&counts[i], hist[i]);
@@ -398,7 +401,7 @@ int fq_build_freq_tables(int device, hipStream_t st, const uint8_t *raw_dev, con
   if (n_recs) {
     const unsigned blocks = (unsigned)min((n_recs + 3) / 4, (size_t)4096);
     uint32_t *err = qual_counts_dev + nq;  // caller provides one extra word
-    hipLaunchKernelGGL(k_hist_seq, dim3(blocks), dim3(256), 0, st, raw_dev, recs_dev, (unsigned)n_recs, seq_counts_dev);
+    hipLaunchKernelGGL(k_hist_seq, dim3(blocks), dim3(256), 0, st, raw_dev, recs_dev, (unsigned)n_recs, seq_counts_dev, err);
     hipLaunchKernelGGL(k_hist_qual, dim3(blocks), dim3(256), 0, st, raw_dev, recs_dev, (unsigned)n_recs,
                        qual_counts_dev, err);
   }

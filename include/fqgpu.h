@@ -41,7 +41,8 @@ enum {
   FQGPU_E_OVERFLOW = -1,   /* stream does not fit the reference capacity rule: endChunk()==0, src/fse_common.hpp:85-90 */
   FQGPU_E_SHORT_READ = -2, /* a read shorter than 3: undefined in the reference (src/fse_quality.cpp:11-12) */
   FQGPU_E_CORRUPT = -3,    /* decode: end mark missing / stream not fully consumed (BIT_endOfDStream, src/fse_common.hpp:141) */
-  FQGPU_E_ARG = -4,        /* bad argument, quality above Q63 (src/fse_quality.cpp:88 throws), bad table */
+  FQGPU_E_ARG = -4,        /* bad argument, quality above Q63 (src/fse_quality.cpp:88 throws), a sequence byte that is
+                            * neither A, C, G, T nor N (base2bits_arr holds UINT_MAX there, src/fse_sequence.cpp:6-14), bad table */
   FQGPU_E_NO_DEVICE = -5,  /* no usable GPU / HIP runtime error: the product path has no CPU fallback */
   FQGPU_E_NOMEM = -6,
   FQGPU_E_HIP = -7
@@ -168,7 +169,9 @@ int fqgpu_dblock_wipe(fqgpu_ctx *ctx, fqgpu_dblock *b);
 /* decodes every block of the batch from its own device-resident streams */
 int fqgpu_dblocks_decode(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks);
 int fqgpu_sync(fqgpu_ctx *ctx);
-/* status/sizes of the last encode/decode of this block (after fqgpu_sync) */
+/* status/sizes of the last encode/decode of this block.  If that operation is still in flight the
+ * call waits for the block's handle first (the lanes run on non-blocking streams), so it never
+ * reports stale or zero sizes; fqgpu_dblock_fetch and fqgpu_dblocks_decode do the same. */
 int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_t *qual_len,
                         size_t *n_pos_len, size_t *n_bases);
 /* diagnostics of the last encode (after fqgpu_sync): the longest run of symbols one lane

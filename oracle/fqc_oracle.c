@@ -19,6 +19,9 @@ static inline unsigned base_code(uint8_t b) {
   default: return 0; /* 'A'; 'N' has been replaced by 'A' before coding */
   }
 }
+/* base2bits_arr (src/fse_sequence.cpp:6-14) holds UINT_MAX for every byte but A, C, G, T: the
+ * reference indexes out of its tables on such input (assert / undefined).  The oracle refuses it. */
+static inline int is_base(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
 static const char CODE_BASE[4] = {'A', 'C', 'G', 'T'};
 
 /* FSE_Sequence::INITIAL_CONTEXT (src/fse_sequence.h:42-63): the four virtual
@@ -51,8 +54,8 @@ static inline unsigned qual_sym(uint8_t c) { return (unsigned)c - 33u; }
 
 /* ------------------------------------------------------------------ */
 
-void fqo_seq_counts(const uint8_t *raw, const fqo_rec *recs, size_t n_recs,
-                    uint32_t counts[FQO_SEQ_MODELS][FQO_SEQ_ALPHA]) {
+int fqo_seq_counts(const uint8_t *raw, const fqo_rec *recs, size_t n_recs,
+                   uint32_t counts[FQO_SEQ_MODELS][FQO_SEQ_ALPHA]) {
   /* FSE_Sequence::calculateFreqTable, src/fse_sequence.cpp:145-169 */
   size_t r, i;
   for (i = 0; i < FQO_SEQ_MODELS; i++)
@@ -63,11 +66,13 @@ void fqo_seq_counts(const uint8_t *raw, const fqo_rec *recs, size_t n_recs,
     for (i = 0; i < recs[r].len; i++) {
       unsigned sym;
       if (s[i] == 'N') continue; /* context is NOT advanced (:156-158) */
+      if (!is_base(s[i])) return FQO_E_ARG;
       sym = base_code(s[i]);
       counts[ctx][sym]++;
       ctx = (ctx >> 2) + (sym << 6); /* addSymUpper, src/fse_sequence.h:22-24 */
     }
   }
+  return FQO_OK;
 }
 
 int fqo_qual_counts(const uint8_t *raw, const fqo_rec *recs, size_t n_recs,
@@ -225,6 +230,8 @@ int fqo_encode_block(fqo_ctx *c, uint8_t *raw, const fqo_rec *recs, size_t n_rec
           n_pos[npos_n++] = (uint16_t)(p - prev);
           s[p] = 'A';
           prev = (uint16_t)p;
+        } else if (!is_base(s[p])) {
+          return FQO_E_ARG;
         }
       }
       n_count[r] = cnt;

@@ -58,8 +58,8 @@ enum {
 };
 
 /* src/fse_sequence.cpp:145-169 / src/fse_quality.cpp:69-97: raw counts (init 1) */
-void fqo_seq_counts(const uint8_t *raw, const fqo_rec *recs, size_t n_recs,
-                    uint32_t counts[FQO_SEQ_MODELS][FQO_SEQ_ALPHA]);
+int fqo_seq_counts(const uint8_t *raw, const fqo_rec *recs, size_t n_recs,
+                   uint32_t counts[FQO_SEQ_MODELS][FQO_SEQ_ALPHA]); /* FQO_E_ARG: a byte outside ACGTN */
 int fqo_qual_counts(const uint8_t *raw, const fqo_rec *recs, size_t n_recs,
                     uint32_t (*counts)[FQO_QUAL_ALPHA]);
 /* src/fse_common.hpp:179-200 */

@@ -58,7 +58,7 @@ def lib():
         L.fo_compress_using_ctable.argtypes = [vp, sz, vp, sz, vp]
         L.fo_decompress_using_dtable.restype = sz
         L.fo_decompress_using_dtable.argtypes = [vp, sz, vp, sz, vp]
-        L.fqo_seq_counts.restype = None
+        L.fqo_seq_counts.restype = C.c_int
         L.fqo_seq_counts.argtypes = [vp, vp, sz, vp]
         L.fqo_qual_counts.restype = i
         L.fqo_qual_counts.argtypes = [vp, vp, sz, vp]
@@ -119,7 +119,8 @@ def freq_tables(raw, recs):
     L = lib()
     sc = np.zeros((SEQ_MODELS, SEQ_ALPHA), dtype=np.uint32)
     qc = np.zeros((QUAL_MODELS, QUAL_ALPHA), dtype=np.uint32)
-    L.fqo_seq_counts(ptr(raw), ptr(recs), len(recs), ptr(sc))
+    rc = L.fqo_seq_counts(ptr(raw), ptr(recs), len(recs), ptr(sc))
+    assert rc == 0, rc
     rc = L.fqo_qual_counts(ptr(raw), ptr(recs), len(recs), ptr(qc))
     assert rc == 0, rc
     sft = np.zeros(1, dtype=SEQ_FT_DTYPE)

@@ -567,6 +567,19 @@ def test_errors(F):
         F.freq_tables(bad, F.parse_fastq(bad))
     assert ei.value.code == -4
     assert ctx.encode_block(bad, F.parse_fastq(bad))["rc"] == -4
+    # bytes that are neither a base nor N: base2bits_arr has UINT_MAX there (src/fse_sequence.cpp:6-14);
+    # coding them as 'A' would lose data silently -> refused by the analysis, the encoder and the oracle
+    for seq in (b"ACgTA", b"ACRTA", b"AC.TA", b"ACGT\r", b"\x00CGTA"):
+        badb = np.frombuffer(b"@r\n" + seq + b"\n+\nIIIII\n@s\nACGTN\n+\nIIII#\n", dtype=np.uint8)
+        br = F.parse_fastq(badb)
+        assert len(br) == 2
+        with pytest.raises(F.FqgpuError) as ei:
+            F.freq_tables(badb, br)
+        assert ei.value.code == -4
+        assert ctx.encode_block(badb, br)["rc"] == -4
+        assert O.OracleCtx(sft, qft).encode(badb, br)["rc"] == -4
+    okb = np.frombuffer(b"@r\nACNTA\n+\nIIIII\n", dtype=np.uint8)
+    assert ctx.encode_block(okb, F.parse_fastq(okb))["rc"] == 0
     # record table pointing outside the block
     r2 = recs[:10].copy()
     r2["qual_off"][3] = raw.size
@@ -577,14 +590,60 @@ def test_errors(F):
     z = g["seq"].copy(); z[-1] = 0
     assert ctx.decode_block(z, g["qual"], g["n_count"], g["n_pos"], recs, skel)[0] == -3
     assert ctx.decode_block(g["seq"][:-5], g["qual"], g["n_count"], g["n_pos"], recs, skel)[0] == -3
-    q = g["qual"].copy(); q[-1] ^= (1 << (int(q[-1]).bit_length() - 1)) | (1 << int(q[-1]).bit_length() % 8)
-    assert ctx.decode_block(g["seq"], q, g["n_count"], g["n_pos"], recs, skel)[0] in (-3, 0) 
+    # damaged bits (end mark moved down by one; a payload bit flipped in the middle of either
+    # stream): the verdict is the oracle's -- refused, or accepted with exactly the oracle's bytes
+    octx = O.OracleCtx(sft, qft)
+    q1 = g["qual"].copy(); top = int(q1[-1]).bit_length() - 1
+    q1[-1] = (int(q1[-1]) & ~(1 << top)) | (1 << (top - 1)) if top > 0 else 0
+    q2 = g["qual"].copy(); q2[q2.size // 2] ^= 0x10
+    s2 = g["seq"].copy(); s2[s2.size // 3] ^= 0x04
+    n_bad = 0
+    for sq, ql in ((g["seq"], q1), (g["seq"], q2), (s2, g["qual"])):
+        orc, oout = octx.decode(sq, ql, g["n_count"], g["n_pos"], recs, skel)
+        rc, out = ctx.decode_block(sq, ql, g["n_count"], g["n_pos"], recs, skel)
+        assert (rc == 0) == (orc == 0), (rc, orc)
+        if rc == 0:
+            assert np.array_equal(out, oout) and not np.array_equal(out, raw)
+        else:
+            assert rc == -3
+            n_bad += 1
+    assert n_bad >= 1  # a stream that is one bit short cannot be consumed exactly
     rc, out = ctx.decode_block(g["seq"], g["qual"], g["n_count"], g["n_pos"], recs, skel)
     assert rc == 0 and np.array_equal(out, raw)
     # tables that do not sum to 2^log are refused
     broken = sft.copy(); broken["norm"][0][7][0] += 1
     with pytest.raises(F.FqgpuError):
         F.Context(broken, qft)
+    ctx.close()
+
+
+def test_results_without_an_explicit_sync(F):
+    """fqgpu_dblock_status / fetch / dblocks_decode right behind an asynchronous encode: the lanes run
+    on non-blocking streams, so these calls wait for the block themselves (they used to read zero sizes)."""
+    raw, recs = _synth(F, 2, 8 << 20)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    b = ctx.dblock(raw, recs)
+    b.encode()
+    rc, st = b.status()          # no ctx.sync() in between
+    assert rc == 0 and st["seq_len"] == len(e["seq"]) and st["qual_len"] == len(e["qual"])
+    b2 = ctx.dblock(raw, recs)
+    b2.encode()
+    g = b2.fetch()               # status + fetch, nothing synchronised by the caller
+    assert np.array_equal(g["seq"], e["seq"]) and np.array_equal(g["qual"], e["qual"])
+    b3 = ctx.dblock(raw, recs)
+    b3.encode()
+    ctx.decode_dblocks([b3])     # encode -> decode back to back
+    rc, _ = b3.status()
+    assert rc == 0 and np.array_equal(b3.fetch_raw(), raw)
+    # a block whose streams were replaced can be re-encoded against its own capacity rule
+    b3.load_streams(np.concatenate([e["seq"], np.zeros(1 << 20, np.uint8)])[: len(e["seq"])], e["qual"], e["n_count"], e["n_pos"])
+    b3.encode()
+    g3 = b3.fetch()
+    assert np.array_equal(g3["seq"], e["seq"])
+    for x in (b, b2, b3):
+        x.close()
     ctx.close()
 
 

@@ -129,3 +129,18 @@ def test_random_blocks_roundtrip(seed):
     bad[-1] ^= 0x80 if bad[-1] < 0x80 else 0xC0
     rc2, _ = ctx.decode(bad, e["qual"], e["n_count"], e["n_pos"], recs, O.blank_skeleton(raw, recs))
     assert rc2 != 0
+
+
+def test_oracle_refuses_bytes_that_are_not_bases(golden_dir):
+    """base2bits_arr (src/fse_sequence.cpp:6-14) knows A, C, G, T only (N is replaced first): the
+    oracle refuses everything else instead of coding it as 'A'."""
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "without_ns.fastq"))
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    octx = O.OracleCtx(sft, qft)
+    assert octx.encode(raw, recs)["rc"] == 0
+    for ch in (b"a", b"R", b".", b"\r"):
+        bad = raw.copy()
+        bad[recs[3]["seq_off"] + 7] = ch[0]
+        assert octx.encode(bad, recs)["rc"] == -4
+        sc = np.zeros((256, 4), dtype=np.uint32)
+        assert O.lib().fqo_seq_counts(O.ptr(bad), O.ptr(recs), len(recs), O.ptr(sc)) == -4

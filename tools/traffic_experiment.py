@@ -5,9 +5,12 @@ line set in the environment (FQGPU_DEBUG_SKIP=<mask>, FQGPU_DEBUG_K1=<bits>, FQG
 FQGPU_DEBUG_NO_ALIAS=1 is set here: enc16 normally lives in the key buffer, so without it a step
 that skips K1 (or its key stores) would partition the previous step's (nb, bits) as if they were
 keys and everything behind K1 would run on garbage -- that made "K1's key stores" look like 3 ms."""
-import os, sys, time
+import os, subprocess, sys, time
 import numpy as np
 sys.path.insert(0, ".")
+# the switches exist only in the experiments build of the library (make experiments)
+subprocess.run(["make", "-C", "fqcomp28_amd/csrc", "-j", "6", "experiments"], check=True, stdout=subprocess.DEVNULL)
+os.environ["FQGPU_LIB"] = os.path.abspath("tools/_build/libfqgpu_experiments.so")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ.setdefault("FQGPU_DEBUG_NO_ALIAS", "1")
 import fqcomp28_amd as F
