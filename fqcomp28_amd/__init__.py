@@ -9,5 +9,5 @@ extension or without a GPU every call raises.
 from .binding import (  # noqa: F401
     FqgpuError, REC_DTYPE, SEQ_FT_DTYPE, QUAL_FT_DTYPE, lib, lib_path, build,
     device_count, bound_seq, bound_qual, parse_fastq, synth_fastq, freq_tables,
-    tables_from_counts, Context, DBlock, F_WRITE_BACK_N, F_DECODE_INDEX,
+    tables_from_counts, Context, DBlock, F_WRITE_BACK_N, F_DECODE_INDEX, memcompress, memdecompress, pinned_empty,
 )

@@ -101,6 +101,11 @@ _PROTOS = {
     "fqgpu_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fqgpu_ctx_last_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "fqgpu_ctx_timing_only": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "fqgpu_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "fqgpu_host_free": (None, [C.c_void_p]),
+    "fqgpu_memcompress_bound": (C.c_size_t, [C.c_size_t]),
+    "fqgpu_memcompress": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "fqgpu_memdecompress": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "fqgpu_parse_fastq": (C.c_long, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "fqgpu_synth_fastq": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_uint64,
                                        C.POINTER(C.c_uint64)]),
@@ -153,6 +158,35 @@ def parse_fastq(raw):
     recs = np.zeros(n, dtype=REC_DTYPE)
     lib().fqgpu_parse_fastq(_p(raw), raw.size, _p(recs), n)
     return recs
+
+
+def memcompress(data):
+    """misc-stream compressor (host code; own format, see fq_misc.cpp) -> uint8 array"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.empty(lib().fqgpu_memcompress_bound(data.size), dtype=np.uint8)
+    n = lib().fqgpu_memcompress(_p(out), out.size, _p(data), data.size)
+    return out[:n].copy()
+
+
+def memdecompress(cdata, original_size):
+    cdata = np.ascontiguousarray(cdata, dtype=np.uint8)
+    out = np.empty(original_size, dtype=np.uint8)
+    n = lib().fqgpu_memdecompress(_p(out), out.size, _p(cdata), cdata.size)
+    if n == 2 ** 64 - 1 or (cdata.size and n != original_size):
+        raise FqgpuError(-3, "memdecompress")
+    return out[:0] if cdata.size == 0 else out
+
+
+def pinned_empty(n_bytes):
+    """uint8 array in page-locked host memory (fqgpu_host_alloc); freed when the array dies"""
+    p = lib().fqgpu_host_alloc(max(1, n_bytes))
+    if not p:
+        raise MemoryError("fqgpu_host_alloc")
+    buf = (C.c_uint8 * max(1, n_bytes)).from_address(p)
+    arr = np.frombuffer(buf, dtype=np.uint8, count=n_bytes)
+    import weakref
+    weakref.finalize(buf, lib().fqgpu_host_free, p)
+    return arr
 
 
 def synth_fastq(n_bytes, mode, seed=28, first_read_id=0):

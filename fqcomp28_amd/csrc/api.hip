@@ -73,6 +73,36 @@ static int use_device(int device) {
   return FQGPU_OK;
 }
 
+// ------------------------------------------------------------------ pinned host memory
+// A 64-byte header in front of the block says how it was allocated (pinned, or plain heap when
+// there is no usable device: host-only tools and tests).
+namespace {
+struct HostHdr { uint64_t magic, pinned, pad[6]; };
+constexpr uint64_t HOST_MAGIC = 0x46514850494E4E44ull;
+}
+extern "C" void *fqgpu_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  int n = 0;
+  const bool gpu = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+  bool pinned = gpu && hipHostMalloc(&p, bytes + sizeof(HostHdr), hipHostMallocDefault) == hipSuccess;
+  if (!pinned) {
+    (void)hipGetLastError();
+    p = aligned_alloc(64, (bytes + sizeof(HostHdr) + 63) & ~(size_t)63);
+    if (!p) return nullptr;
+  }
+  HostHdr *h = static_cast<HostHdr *>(p);
+  h->magic = HOST_MAGIC;
+  h->pinned = pinned ? 1 : 0;
+  return h + 1;
+}
+extern "C" void fqgpu_host_free(void *p) {
+  if (!p) return;
+  HostHdr *h = static_cast<HostHdr *>(p) - 1;
+  if (h->magic != HOST_MAGIC) return;  // not ours
+  h->magic = 0;
+  if (h->pinned) (void)hipHostFree(h); else free(h);
+}
+
 // ------------------------------------------------------------------ kernel timing
 // Spans = pairs of HIP events recorded on the stream the kernels run on.  Spans accumulate
 // from fqgpu_ctx_enable_timing(ctx, 1) until they are read; fqgpu_ctx_last_timing sums them
@@ -383,6 +413,8 @@ extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < FQ_MAX_LANES; i++) free_lane(ctx->lanes[i]);
   if (ctx->hp_block) fqgpu_dblock_destroy(ctx->hp_block);
+  if (ctx->hp_ev_h2d) (void)hipEventDestroy(ctx->hp_ev_h2d);
+  if (ctx->hp_result) (void)hipHostFree(ctx->hp_result);
   if (ctx->timer) {
     for (hipEvent_t e : ctx->timer->pool) (void)hipEventDestroy(e);
     delete ctx->timer;
@@ -799,6 +831,16 @@ static int hp_block_acquire(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_
   return FQGPU_OK;
 }
 
+// Host-pointer encode, one block per call, as asynchronous as one call can be: the inputs go up on
+// the handle's copy stream, the lane's kernels wait for that event (not for the host), the result
+// block lands in page-locked memory behind the last kernel, and the streams come down with their
+// exact sizes on the stream the encode ran on.  The host waits twice: for the sizes, for the
+// streams.  With page-locked caller buffers (fqgpu_host_alloc; the shim's chunk and stream vectors
+// use it) every copy runs at link rate and several worker threads -- one handle each, like the
+// reference's one workspace per thread (src/process.cpp:49-54) -- overlap their copies with each
+// other's kernels.  Pageable buffers work too, at the rate of the runtime's staging copies.
+// N -> A write-back happens on the HOST from n_count / n_pos (a few thousand bytes to touch)
+// instead of copying the whole raw block back over PCIe.
 extern "C" int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, const fqgpu_rec *recs,
                                   size_t n_recs, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
                                   uint8_t *qual_out, size_t qual_cap, size_t *qual_len,
@@ -814,21 +856,51 @@ extern "C" int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, 
   // for the worst case (every base an N) instead of pre-counting the N's on the host.
   fqgpu_dblock *b = nullptr;
   if ((rc = hp_block_acquire(ctx, raw_len, n_recs, n_bases, seq_cap, qual_cap, n_bases, &b))) return rc;
+  if (!ctx->hp_ev_h2d) FQ_HIP(hipEventCreateWithFlags(&ctx->hp_ev_h2d, hipEventDisableTiming));
+  if (!ctx->hp_result) FQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->hp_result), sizeof(BlockResult), hipHostMallocDefault));
   FQ_HIP(hipMemcpyAsync(b->raw, raw, raw_len, hipMemcpyHostToDevice, ctx->stream));
   FQ_HIP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, ctx->stream));
-  FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), ctx->stream));
-  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  FQ_HIP(hipEventRecord(ctx->hp_ev_h2d, ctx->stream));
   b->last_op = 1;
-  if ((rc = fq_encode_launch(ctx, b, flags))) return rc;
-  if ((rc = fqgpu_sync(ctx))) return rc;
-  if ((rc = pull_result(b, true))) return rc;
+  b->result_pulled = false;
+  hipStream_t st = nullptr;
+  // (the device copy of raw is scratch here: its N's are patched on the host below)
+  if ((rc = fq_encode_launch(ctx, b, flags & ~FQGPU_F_WRITE_BACK_N, ctx->hp_ev_h2d, &st))) return rc;
+  FQ_HIP(hipMemcpyAsync(ctx->hp_result, b->result, sizeof(BlockResult), hipMemcpyDeviceToHost, st));
+  FQ_HIP(hipStreamSynchronize(st));
+  b->host_result = *ctx->hp_result;
+  b->result_pulled = true;
+  {
+    const BlockResult &r = b->host_result;
+    if (r.s[0].bad_symbol || r.s[1].bad_symbol) return FQGPU_E_ARG;
+    if (r.s[0].overflow || r.s[1].overflow) return FQGPU_E_OVERFLOW;
+    b->seq_len = (size_t)r.s[0].len; b->qual_len = (size_t)r.s[1].len; b->n_pos_len = (size_t)r.n_pos_len;
+  }
   if (n_pos_out && b->n_pos_len > n_pos_cap) return FQGPU_E_ARG;
-  rc = fqgpu_dblock_fetch(ctx, b, seq_out, qual_out, readlens_out, n_count_out, n_pos_out,
-                          (flags & FQGPU_F_WRITE_BACK_N) ? raw : nullptr);
+  // N -> A on the host needs the N tables even if the caller does not want them
+  std::vector<uint16_t> tmp_cnt, tmp_pos;
+  const bool patch = (flags & FQGPU_F_WRITE_BACK_N) && b->n_pos_len;
+  uint16_t *cnt_h = n_count_out, *pos_h = n_pos_out;
+  if (patch && !cnt_h) { tmp_cnt.resize(n_recs); cnt_h = tmp_cnt.data(); }
+  if (patch && !pos_h) { tmp_pos.resize(b->n_pos_len); pos_h = tmp_pos.data(); }
+  FQ_HIP(hipMemcpyAsync(seq_out, b->seq, b->seq_len, hipMemcpyDeviceToHost, st));
+  FQ_HIP(hipMemcpyAsync(qual_out, b->qual, b->qual_len, hipMemcpyDeviceToHost, st));
+  if (readlens_out) FQ_HIP(hipMemcpyAsync(readlens_out, b->readlens, n_recs * 2, hipMemcpyDeviceToHost, st));
+  if (cnt_h) FQ_HIP(hipMemcpyAsync(cnt_h, b->n_count, n_recs * 2, hipMemcpyDeviceToHost, st));
+  if (pos_h && b->n_pos_len) FQ_HIP(hipMemcpyAsync(pos_h, b->n_pos, b->n_pos_len * 2, hipMemcpyDeviceToHost, st));
+  FQ_HIP(hipStreamSynchronize(st));
+  if (patch) {  // replaceAndEncodeNs (src/fse_sequence.cpp:35-51): deltas to the previous N, the first one absolute
+    size_t at = 0;
+    for (size_t r = 0; r < n_recs; r++) {
+      uint8_t *s = raw + recs[r].seq_off;
+      unsigned pos = 0;
+      for (unsigned k = cnt_h[r]; k > 0; k--) { pos += pos_h[at++]; s[pos] = 'A'; }
+    }
+  }
   *seq_len = b->seq_len;
   *qual_len = b->qual_len;
   if (n_pos_len) *n_pos_len = b->n_pos_len;
-  return rc;
+  return FQGPU_OK;
 }
 
 extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual,
@@ -847,17 +919,29 @@ extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq
   const size_t qual_cap = qual_len > fqgpu_bound_qual(n_bases) ? qual_len : fqgpu_bound_qual(n_bases);
   if ((rc = hp_block_acquire(ctx, raw_len, n_recs, n_bases, seq_cap, qual_cap, n_pos_len, &b))) return rc;
   // raw_out holds the skeleton the first decode pass laid out (headers, newlines, '+')
-  FQ_HIP(hipMemcpyAsync(b->raw, raw_out, raw_len, hipMemcpyHostToDevice, ctx->stream));
-  FQ_HIP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, ctx->stream));
-  FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), ctx->stream));
-  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  // everything on the handle's stream (the decode kernels run there too): no host wait in between
+  hipStream_t st = ctx->stream;
+  FQ_HIP(hipMemcpyAsync(b->raw, raw_out, raw_len, hipMemcpyHostToDevice, st));
+  FQ_HIP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, st));
+  FQ_HIP(hipMemsetAsync(b->seq + seq_len, 0, 16, st));  // the bit reader loads whole dwords
+  FQ_HIP(hipMemsetAsync(b->qual + qual_len, 0, 16, st));
+  FQ_HIP(hipMemcpyAsync(b->seq, seq, seq_len, hipMemcpyHostToDevice, st));
+  FQ_HIP(hipMemcpyAsync(b->qual, qual, qual_len, hipMemcpyHostToDevice, st));
   // the reference pops from the END of n_count (src/fse_sequence.cpp:115-126)
-  if ((rc = fqgpu_dblock_load_streams(ctx, b, seq, seq_len, qual, qual_len, n_count + (n_count_len - n_recs),
-                                      n_pos, n_pos_len))) return rc;
+  FQ_HIP(hipMemcpyAsync(b->n_count, n_count + (n_count_len - n_recs), n_recs * 2, hipMemcpyHostToDevice, st));
+  if (n_pos_len) FQ_HIP(hipMemcpyAsync(b->n_pos, n_pos, n_pos_len * 2, hipMemcpyHostToDevice, st));
+  b->seq_len = seq_len; b->qual_len = qual_len; b->n_pos_len = n_pos_len;
   b->last_op = 2;
+  b->result_pulled = false;
   fqgpu_dblock *one[1] = {b};
   if ((rc = fq_decode_launch(ctx, one, 1))) return rc;
-  if ((rc = fqgpu_sync(ctx))) return rc;
-  if ((rc = pull_result(b, false))) return rc;
-  return fqgpu_dblock_fetch(ctx, b, nullptr, nullptr, nullptr, nullptr, nullptr, raw_out);
+  if (!ctx->hp_result) FQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->hp_result), sizeof(BlockResult), hipHostMallocDefault));
+  FQ_HIP(hipMemcpyAsync(ctx->hp_result, b->result, sizeof(BlockResult), hipMemcpyDeviceToHost, st));
+  FQ_HIP(hipMemcpyAsync(raw_out, b->raw, raw_len, hipMemcpyDeviceToHost, st));
+  FQ_HIP(hipStreamSynchronize(st));
+  b->host_result = *ctx->hp_result;
+  b->result_pulled = true;
+  if (b->host_result.s[0].bad_symbol || b->host_result.s[1].bad_symbol) return FQGPU_E_ARG;
+  if (b->host_result.s[0].corrupt || b->host_result.s[1].corrupt) return FQGPU_E_CORRUPT;
+  return FQGPU_OK;
 }

@@ -382,14 +382,16 @@ int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered) {
 // after the record-level kernels and joined before the N-position pass.  Blocks handed to
 // different lanes overlap on the device: the serial sequence chains of one block hide behind
 // the bandwidth-bound passes of the others.
-int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags) {
+int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t wait, hipStream_t *done) {
   const unsigned R = (unsigned)b->n_recs;
   if (R == 0 || b->n_bases == 0) return FQGPU_E_ARG;
   EncLane *lp = fq_next_lane(ctx);
   if (!lp) return FQGPU_E_NOMEM;
   EncLane &lane = *lp;
   hipStream_t st = lane.st_seq;
+  if (done) *done = st;
   int rc;
+  if (wait) FQ_HIP(hipStreamWaitEvent(st, wait, 0));
   if ((rc = lane.rec_start.reserve((size_t)(R + 1) * 4))) return rc;
   if ((rc = lane.n_cnt32.reserve((size_t)R * 4 * 2))) return rc;  // n_cnt32 | lens32
   if ((rc = lane.n_off.reserve((size_t)(R + 1) * 4))) return rc;

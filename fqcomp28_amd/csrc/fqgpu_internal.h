@@ -150,6 +150,8 @@ struct fqgpu_ctx {
   // staging block of the host-pointer calls, kept between calls (grow-only device buffers)
   fqgpu_dblock *hp_block = nullptr;
   size_t hp_raw = 0, hp_recs = 0, hp_seq = 0, hp_qual = 0, hp_side = 0, hp_npos = 0;  // allocated elements
+  hipEvent_t hp_ev_h2d = nullptr;     // "the block's inputs have arrived": the lane's streams wait for it
+  BlockResult *hp_result = nullptr;   // page-locked landing place of the result block
 };
 
 EncLane *fq_next_lane(fqgpu_ctx *ctx);  // api.hip: round-robin, creates streams on first use
@@ -203,7 +205,11 @@ int fq_normalize_counts(hipStream_t st, const uint32_t *counts_dev, int n_models
                         int16_t *norm_dev, uint32_t *logs_dev, uint32_t *max_log_dev, uint32_t *err_dev);
 int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint32_t *err_dev);
 
-int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags);
+// wait: event the lane's first kernel waits for (inputs arriving on another stream), or nullptr;
+// done: receives the stream on which the block's last kernel was launched (copies of the results
+// ordered behind the encode go there), may be nullptr
+int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t wait = nullptr,
+                     hipStream_t *done = nullptr);
 int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered);
 int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks);
 int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);

@@ -1,0 +1,160 @@
+// process.hpp -- the reference's block pipeline (src/process.cpp:32-105) over the GPU workspaces:
+// N worker threads, each owning chunk + buffers + workspace (src/process.cpp:49-54, 95-98), pull
+// whole blocks from a mutex-protected reader, code them, and hand them to a mutex-protected
+// writer; blocks land in the archive in COMPLETION order and the index records chunk_idx
+// (src/archive.cpp:57-106, src/archive.h:85-89).
+//
+// What is new against the reference is only where a worker's workspace lives: worker t of T uses
+// GPU devices[t mod G] (blocks are independent given the tables, every GPU holds a
+// replica of them, no collective, no peer traffic).  With T > G several workers share a GPU; each
+// has its own handle (own streams, own staging block in HBM), so worker A's H2D copy, worker B's
+// kernels and worker C's D2H copy overlap on the device -- the chunk and stream buffers are
+// page-locked (workspace.hpp: HostAllocator), the copies asynchronous (api.hip: fqgpu_encode_block).
+#pragma once
+
+#include <atomic>
+#include <chrono>
+#include <exception>
+#include <functional>
+#include <thread>
+
+#include "archive.hpp"
+
+namespace fqcomp28 {
+
+struct Settings {  // the part of src/settings.h:36-50 this path needs, plus the device list
+  unsigned n_threads = 1;
+  std::size_t reading_chunk_size = std::size_t(256) << 20;  // -R, MiB
+  std::size_t sample_chunk_size = std::size_t(128) << 20;   // -S, MiB
+  std::vector<int> devices = {0};
+  /** The reference never clears cbs.n_count / cbs.n_pos (src/compressed_buffers.h:58-68), so block k
+   *  of a worker carries the N tables of all its earlier blocks in front (decode pops
+   *  from the end, so both forms decode everywhere).  Default: fresh tables per block -- the
+   *  accumulation makes misc-stream work grow quadratically with the number of blocks. */
+  bool accumulate_n_buffers = false;
+};
+
+struct InputStats {  // src/report.h
+  std::size_t seq = 0, header = 0, n_records = 0, raw = 0;
+  InputStats &operator+=(const InputStats &o) { seq += o.seq; header += o.header; n_records += o.n_records; raw += o.raw; return *this; }
+};
+struct CompressedStats {
+  std::size_t seq = 0, qual = 0, misc = 0, n_blocks = 0;
+  CompressedStats &operator+=(const CompressedStats &o) { seq += o.seq; qual += o.qual; misc += o.misc; n_blocks += o.n_blocks; return *this; }
+};
+struct FarmReport {
+  InputStats in;
+  CompressedStats out;
+  double seconds = 0;          // wall clock over the worker threads (tables and handles built before)
+  std::vector<unsigned> blocks_per_worker;
+};
+
+namespace detail {
+inline std::size_t miscBytes(const CompressedBuffersDst &cbs) {
+  std::size_t n = cbs.compressed_readlens.size() + cbs.compressed_n_count.size() + cbs.compressed_n_pos.size();
+  for (const auto &f : cbs.compressed_header_fields) n += f.isDifferentFlag.size() + f.content.size() + f.contentLength.size();
+  return n;
+}
+/** runs body(t) on n threads; the first exception of any worker is rethrown after all have joined */
+template <class Body> void runWorkers(unsigned n, Body &&body) {
+  std::vector<std::thread> threads;
+  std::vector<std::exception_ptr> errors(n);
+  threads.reserve(n);
+  for (unsigned t = 0; t < n; ++t)
+    threads.emplace_back([&, t] {
+      try { body(t); } catch (...) { errors[t] = std::current_exception(); }
+    });
+  for (auto &th : threads) th.join();
+  for (auto &e : errors) if (e) std::rethrow_exception(e);
+}
+}  // namespace detail
+
+/** The compression farm: `next_chunk(chunk)` and `write_block(cbs)` are called concurrently from
+ *  the workers and must be thread-safe (FastqReader::readNextChunk and Archive::writeBlock are). */
+template <class Source, class Sink>
+FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&write_block, const Settings &set) {
+  const unsigned T = std::max(1u, set.n_threads);
+  if (set.devices.empty()) throw std::invalid_argument("compressFarm: no device");
+  // every worker builds its workspace first (256 + 8192 tables on its GPU: the reference does the
+  // same once per thread, src/workspace.h:62-64); the clock starts when all are ready
+  std::vector<std::unique_ptr<CompressionWorkspace>> wksp(T);
+  detail::runWorkers(T, [&](unsigned t) { wksp[t] = std::make_unique<CompressionWorkspace>(&meta, set.devices[t % set.devices.size()]); });
+  std::vector<InputStats> istats(T);
+  std::vector<CompressedStats> cstats(T);
+  FarmReport rep;
+  rep.blocks_per_worker.assign(T, 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  detail::runWorkers(T, [&](unsigned t) {
+    FastqChunk chunk;
+    CompressedBuffersDst cbs;
+    while (next_chunk(chunk)) {
+      istats[t].seq += chunk.tot_reads_length;
+      istats[t].header += chunk.headers_length;
+      istats[t].n_records += chunk.records.size();
+      istats[t].raw += chunk.raw_data.size();
+      if (!set.accumulate_n_buffers) { cbs.n_count.clear(); cbs.n_pos.clear(); }
+      wksp[t]->encodeChunk(chunk, cbs);
+      cstats[t].seq += cbs.seq.size();
+      cstats[t].qual += cbs.qual.size();
+      cstats[t].misc += detail::miscBytes(cbs);
+      cstats[t].n_blocks++;
+      rep.blocks_per_worker[t]++;
+      write_block(cbs);
+    }
+  });
+  rep.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (unsigned t = 0; t < T; ++t) { rep.in += istats[t]; rep.out += cstats[t]; }
+  return rep;
+}
+
+/** processReads (src/process.cpp:32-82): file in, archive out */
+inline FarmReport processReads(const path_t &mates1, const path_t &archive_path, const Settings &set) {
+  Archive archive(archive_path, mates1, set.sample_chunk_size, set.devices.at(0));
+  FastqReader reader(mates1.string(), set.reading_chunk_size);
+  FarmReport rep = compressFarm(
+      archive.meta(), [&](FastqChunk &c) { return reader.readNextChunk(c); },
+      [&](const CompressedBuffersDst &cbs) { archive.writeBlock(cbs); }, set);
+  archive.writeIndex();
+  archive.flush();
+  return rep;
+}
+
+/** The decompression farm (src/process.cpp:84-105): `next_block(cbs)` / `write_chunk(chunk)` thread-safe */
+template <class Source, class Sink>
+FarmReport decompressFarm(const DatasetMeta &meta, Source &&next_block, Sink &&write_chunk, const Settings &set) {
+  const unsigned T = std::max(1u, set.n_threads);
+  if (set.devices.empty()) throw std::invalid_argument("decompressFarm: no device");
+  std::vector<std::unique_ptr<DecompressionWorkspace>> wksp(T);
+  detail::runWorkers(T, [&](unsigned t) { wksp[t] = std::make_unique<DecompressionWorkspace>(&meta, set.devices[t % set.devices.size()]); });
+  std::vector<InputStats> istats(T);
+  FarmReport rep;
+  rep.blocks_per_worker.assign(T, 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  detail::runWorkers(T, [&](unsigned t) {
+    CompressedBuffersSrc cbs;
+    FastqChunk chunk;
+    while (next_block(cbs)) {
+      wksp[t]->decodeChunk(chunk, cbs);
+      istats[t].raw += chunk.raw_data.size();
+      istats[t].n_records += chunk.records.size();
+      rep.blocks_per_worker[t]++;
+      write_chunk(chunk);
+    }
+  });
+  rep.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (unsigned t = 0; t < T; ++t) rep.in += istats[t];
+  return rep;
+}
+
+/** processArchiveParts (src/process.cpp:84-105): archive in, file out (chunks in original order) */
+inline FarmReport processArchiveParts(const path_t &archive_path, const path_t &mates1_out, const Settings &set) {
+  Archive archive(archive_path);
+  FastqWriter writer(mates1_out.string());
+  FarmReport rep = decompressFarm(
+      archive.meta(), [&](CompressedBuffersSrc &cbs) { return archive.readBlock(cbs); },
+      [&](const FastqChunk &chunk) { writer.writeChunk(chunk); }, set);
+  writer.flush();
+  return rep;
+}
+
+}  // namespace fqcomp28

@@ -12,8 +12,10 @@
 //   CompressionWorkspace::encodeHeader / DecompressionWorkspace::decodeHeader   src/workspace.cpp:95-157
 // The seq/qual FSE streams are coded on the GPU; the header fields are tokenised and delta-coded
 // on the host (headers.hpp).  The misc streams (readlens, n_count, n_pos,
-// header fields) are left as they are BEFORE the reference's libbsc pass (src/workspace.cpp:176-236:
-// libbsc's source is absent); cbs.original_size carries their sizes as that pass would record them.
+// header fields) go through compressMiscBuffers / decompressMiscBuffers like in the reference
+// (src/workspace.cpp:176-256) -- with the library's own coder (fq_misc.cpp) in place of libbsc, whose
+// source is absent: the compressed misc BYTES are out of parity scope, everything in front of that
+// pass (the streams themselves, cbs.original_size) is the reference's, byte for byte.
 // Error behaviour:
 // the reference asserts / silently returns size 0; this shim throws std::runtime_error with
 // fqgpu_strerror().  Header-only; link with libfqgpu.so.
@@ -24,6 +26,7 @@
 #include <cstring>
 #include <istream>
 #include <memory>
+#include <new>
 #include <ostream>
 #include <stdexcept>
 #include <string>
@@ -36,7 +39,25 @@
 namespace fqcomp28 {
 
 using readlen_t = uint16_t;  // src/defs.h:14
-using FastqData = std::vector<char>;
+
+/** Allocator of the buffers that cross PCIe: page-locked host memory (fqgpu_host_alloc), so that
+ *  the copies to and from the GPU run at link rate and asynchronously.  The reference's
+ *  FastqData / std::vector<std::byte> with another allocator: same interface, same contents. */
+template <class T> struct HostAllocator {
+  using value_type = T;
+  HostAllocator() = default;
+  template <class U> HostAllocator(const HostAllocator<U> &) {}
+  T *allocate(std::size_t n) {
+    void *p = fqgpu_host_alloc(n * sizeof(T));
+    if (!p) throw std::bad_alloc();
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, std::size_t) { fqgpu_host_free(p); }
+  template <class U> bool operator==(const HostAllocator<U> &) const { return true; }
+  template <class U> bool operator!=(const HostAllocator<U> &) const { return false; }
+};
+using FastqData = std::vector<char, HostAllocator<char>>;            // src/defs.h:20
+using stream_bytes_t = std::vector<std::byte, HostAllocator<std::byte>>;  // cbs.seq / cbs.qual
 
 /** Non-owning - holds pointers into outside allocated data (src/defs.h:22-32) */
 struct FastqRecord {
@@ -69,13 +90,35 @@ struct cb_original_sizes_t {  // src/compressed_buffers.h:10-32
 };
 
 struct CompressedBuffers {  // src/compressed_buffers.h:34-69
-  std::vector<std::byte> seq, qual, readlens, n_count, n_pos;
+  stream_bytes_t seq, qual;
+  std::vector<std::byte> readlens, compressed_readlens;
+  std::vector<headers::CompressedFieldStorage> compressed_header_fields;
+  std::vector<std::byte> n_count, compressed_n_count;
+  std::vector<std::byte> n_pos, compressed_n_pos;
   cb_original_sizes_t original_size;
   uint32_t chunk_idx = 0;
   /* like the reference, clear() does NOT clear n_count / n_pos */
-  virtual void clear() { seq.clear(); qual.clear(); readlens.clear(); original_size.clear(); }
+  virtual void clear() {
+    seq.clear(); qual.clear();
+    readlens.clear(); compressed_readlens.clear();
+    for (auto &chf : compressed_header_fields) chf.clear();
+    original_size.clear();
+  }
   virtual ~CompressedBuffers() = default;
 };
+
+/** memcompress / memdecompress (src/memcompress.h:5-28) over the library's own misc-stream coder
+ *  (fq_misc.cpp; libbsc's bytes are out of parity scope) */
+inline std::size_t memcompress(std::byte *dst, const std::byte *src, std::size_t src_size) {
+  return fqgpu_memcompress(reinterpret_cast<uint8_t *>(dst), fqgpu_memcompress_bound(src_size),
+                           reinterpret_cast<const uint8_t *>(src), src_size);
+}
+inline std::size_t memdecompress(std::byte *dst, std::size_t dst_size, const std::byte *src, std::size_t src_size) {
+  const std::size_t n = fqgpu_memdecompress(reinterpret_cast<uint8_t *>(dst), dst_size,
+                                            reinterpret_cast<const uint8_t *>(src), src_size);
+  if (n == static_cast<std::size_t>(-1) || (src_size && n != dst_size)) throw std::runtime_error("memdecompress: malformed misc stream");
+  return n;
+}
 struct CompressedBuffersDst : CompressedBuffers {
   std::vector<headers::FieldStorageDst> header_fields;
   void clear() override {
@@ -218,9 +261,48 @@ public:
     cbs.original_size.readlens = static_cast<uint32_t>(cbs.readlens.size());
     cbs.original_size.n_count = static_cast<uint32_t>(cbs.n_count.size());
     cbs.original_size.n_pos = static_cast<uint32_t>(cbs.n_pos.size());
+    compressMiscBuffers(cbs);
+  }
+
+  /** CompressionWorkspace::compressMiscBuffers (src/workspace.cpp:176-213): readlens, n_count, n_pos
+   *  and every header field stream through memcompress; original sizes recorded for the container */
+  void compressMiscBuffers(CompressedBuffersDst &cbs) const { compressMiscBuffers(cbs, fmt_); }
+  /** the same without a workspace (host-only tools and tests: no GPU involved) */
+  static void compressMiscBuffers(CompressedBuffersDst &cbs, const headers::HeaderFormatSpeciciation &fmt_) {
+    cbs.original_size.readlens = static_cast<uint32_t>(cbs.readlens.size());
+    compressBuffer(cbs.compressed_readlens, cbs.readlens);
+    cbs.original_size.n_count = static_cast<uint32_t>(cbs.n_count.size());
+    compressBuffer(cbs.compressed_n_count, cbs.n_count);
+    cbs.original_size.n_pos = static_cast<uint32_t>(cbs.n_pos.size());
+    compressBuffer(cbs.compressed_n_pos, cbs.n_pos);
+    cbs.compressed_header_fields.resize(fmt_.n_fields());
+    cbs.original_size.header_fields.resize(fmt_.n_fields());
+    for (std::size_t i = 0, E = fmt_.n_fields(); i < E; ++i) {
+      const auto &field_data = cbs.header_fields[i];
+      auto &field_cdata = cbs.compressed_header_fields[i];
+      auto &original_size = cbs.original_size.header_fields[i];
+      if (fmt_.field_types[i] == headers::FieldType::STRING) {
+        compressBuffer(field_cdata.isDifferentFlag, field_data.isDifferentFlag);
+        compressBuffer(field_cdata.content, field_data.content);
+        compressBuffer(field_cdata.contentLength, field_data.contentLength);
+        original_size = field_data.originalSizes();
+      } else { /* NUMERIC */
+        compressBuffer(field_cdata.content, field_data.content);
+        field_cdata.isDifferentFlag.clear(); field_cdata.contentLength.clear();
+        original_size = {};
+        original_size.content = static_cast<uint32_t>(field_data.content.size());
+      }
+    }
   }
 
 private:
+  /** compressBuffer (src/workspace.cpp:258-265) */
+  static std::size_t compressBuffer(std::vector<std::byte> &dst, const std::vector<std::byte> &src) {
+    dst.resize(fqgpu_memcompress_bound(src.size()));
+    const std::size_t csize = memcompress(dst.data(), src.data(), src.size());
+    dst.resize(csize);
+    return csize;
+  }
   static void append(std::vector<std::byte> &dst, const uint16_t *src, std::size_t n) {
     const std::size_t old = dst.size();
     dst.resize(old + n * sizeof(uint16_t));
@@ -241,6 +323,7 @@ public:
     chunk.raw_data.resize(cbs.original_size.total);
     chunk.records.resize(cbs.original_size.n_records);
     startNewChunk();
+    decompressMiscBuffers(cbs);
     if (cbs.header_fields.size() != fmt_.n_fields()) throw std::invalid_argument("decodeChunk: header field streams do not match the format");
     if (cbs.readlens.size() < chunk.records.size() * sizeof(readlen_t)) throw std::invalid_argument("decodeChunk: readlens too short");
     char *dst = chunk.raw_data.data();
@@ -268,6 +351,38 @@ public:
                                   cbs.index.n_pos / sizeof(uint16_t), recs.data(), recs.size(),
                                   reinterpret_cast<uint8_t *>(chunk.raw_data.data()), chunk.raw_data.size()),
                "decodeChunk");
+  }
+
+  /** DecompressionWorkspace::decompressMiscBuffers (src/workspace.cpp:215-256): every misc stream
+   *  is restored from its compressed twin to the size the container recorded; index.n_count /
+   *  index.n_pos are set to the ends of the buffers (the decoder pops from there) */
+  void decompressMiscBuffers(CompressedBuffersSrc &cbs) const { decompressMiscBuffers(cbs, fmt_); }
+  static void decompressMiscBuffers(CompressedBuffersSrc &cbs, const headers::HeaderFormatSpeciciation &fmt_) {
+    cbs.readlens.resize(cbs.original_size.readlens);
+    memdecompress(cbs.readlens.data(), cbs.readlens.size(), cbs.compressed_readlens.data(), cbs.compressed_readlens.size());
+    cbs.index.n_count = cbs.original_size.n_count;
+    cbs.n_count.resize(cbs.original_size.n_count);
+    memdecompress(cbs.n_count.data(), cbs.n_count.size(), cbs.compressed_n_count.data(), cbs.compressed_n_count.size());
+    cbs.index.n_pos = cbs.original_size.n_pos;
+    cbs.n_pos.resize(cbs.original_size.n_pos);
+    memdecompress(cbs.n_pos.data(), cbs.n_pos.size(), cbs.compressed_n_pos.data(), cbs.compressed_n_pos.size());
+    if (cbs.compressed_header_fields.size() != fmt_.n_fields() || cbs.original_size.header_fields.size() != fmt_.n_fields())
+      throw std::invalid_argument("decodeChunk: header field streams do not match the format");
+    cbs.header_fields.resize(fmt_.n_fields());
+    for (std::size_t i = 0, E = fmt_.n_fields(); i < E; ++i) {
+      const auto &field_cdata = cbs.compressed_header_fields[i];
+      const auto &original_size = cbs.original_size.header_fields[i];
+      auto &field_data = cbs.header_fields[i];
+      field_data.clear();
+      field_data.content.resize(original_size.content);
+      memdecompress(field_data.content.data(), field_data.content.size(), field_cdata.content.data(), field_cdata.content.size());
+      if (fmt_.field_types[i] == headers::FieldType::STRING) {
+        field_data.isDifferentFlag.resize(original_size.isDifferentFlag);
+        field_data.contentLength.resize(original_size.contentLength);
+        memdecompress(field_data.isDifferentFlag.data(), field_data.isDifferentFlag.size(), field_cdata.isDifferentFlag.data(), field_cdata.isDifferentFlag.size());
+        memdecompress(field_data.contentLength.data(), field_data.contentLength.size(), field_cdata.contentLength.data(), field_cdata.contentLength.size());
+      }
+    }
   }
 
 private:

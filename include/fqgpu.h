@@ -222,6 +222,24 @@ long fqgpu_parse_fastq(const uint8_t *raw, size_t len, fqgpu_rec *recs, size_t c
 size_t fqgpu_synth_fastq(uint8_t *dst, size_t cap, int mode, uint64_t seed, uint64_t first_read_id,
                          uint64_t *n_reads_out);
 
+
+/* Pinned (page-locked) host memory for the buffers that cross PCIe: the shim's FastqChunk::raw_data
+ * and CompressedBuffers::seq/qual live in it, so that fqgpu_encode_block / fqgpu_decode_block copy
+ * at the full link rate and asynchronously.  Without a usable GPU the memory is ordinary heap
+ * memory (host-only tools and tests still run); there is still no compute fallback. */
+void *fqgpu_host_alloc(size_t bytes);
+void fqgpu_host_free(void *p);
+
+/* memcompress / memdecompress (src/memcompress.h:5-28) for the misc streams -- readlens, n_count,
+ * n_pos and the header field streams, src/workspace.cpp:176-256.  The reference uses libbsc
+ * (third party, source absent): the compressed BYTES are this library's own format and out of
+ * parity scope; the contract is the reference's: dst holds src_size + 28 bytes
+ * (extra_csize_misc, src/workspace.h:18), empty in = empty out, the original size travels in the
+ * container.  fqgpu_memdecompress returns dst_size, 0 for an empty input, (size_t)-1 if malformed. */
+size_t fqgpu_memcompress_bound(size_t src_size);
+size_t fqgpu_memcompress(uint8_t *dst, size_t dst_cap, const uint8_t *src, size_t src_size);
+size_t fqgpu_memdecompress(uint8_t *dst, size_t dst_size, const uint8_t *src, size_t src_size);
+
 #ifdef __cplusplus
 }
 #endif

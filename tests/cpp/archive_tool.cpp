@@ -1,0 +1,81 @@
+// Host-only exerciser of the shim's container code (fqcomp28_amd/csrc/archive.hpp) -- no GPU call:
+//   archive_tool copy <in.fqc> <out.fqc>      readBlock every block (index order) -> writeBlock -> writeIndex
+//   archive_tool dump <in.fqc>                per block: idx, sizes, and the misc streams after
+//                                             decompressMiscBuffers + header decoding, as hex / text
+// tests/test_archive.py drives it against oracle/fqc_archive.py (an independent Python reading of
+// src/archive.h:10-17, src/archive.cpp:57-106).
+#include "../../fqcomp28_amd/csrc/archive.hpp"
+
+#include <cstdio>
+
+using namespace fqcomp28;
+
+static CompressedBuffersDst toDst(CompressedBuffersSrc &&in) {
+  CompressedBuffersDst d;
+  d.original_size = in.original_size;
+  d.chunk_idx = in.chunk_idx;
+  d.seq = std::move(in.seq);
+  d.qual = std::move(in.qual);
+  d.compressed_readlens = std::move(in.compressed_readlens);
+  d.compressed_n_count = std::move(in.compressed_n_count);
+  d.compressed_n_pos = std::move(in.compressed_n_pos);
+  d.compressed_header_fields = std::move(in.compressed_header_fields);
+  return d;
+}
+
+static void hex(const char *name, const std::vector<std::byte> &v) {
+  std::printf("%s %zu ", name, v.size());
+  for (std::byte b : v) std::printf("%02x", static_cast<unsigned>(b));
+  std::printf("\n");
+}
+
+int main(int argc, char **argv) {
+  try {
+    if (argc == 4 && std::string(argv[1]) == "copy") {
+      Archive in(argv[2]);
+      DatasetMeta meta(std::string_view(in.meta().first_header));
+      std::memcpy(meta.ft_seq.get(), in.meta().ft_seq.get(), FQGPU_SEQ_FT_BYTES);
+      std::memcpy(meta.ft_qual.get(), in.meta().ft_qual.get(), FQGPU_QUAL_FT_BYTES);
+      Archive out(argv[3], std::move(meta));
+      CompressedBuffersSrc cbs;
+      std::size_t n = 0;
+      while (in.readBlock(cbs)) { out.writeBlock(toDst(std::move(cbs))); ++n; }
+      out.writeIndex();
+      out.flush();
+      std::printf("copied %zu blocks, index %zu bytes\n", n, out.indexBytes());
+      return 0;
+    }
+    if (argc == 3 && std::string(argv[1]) == "dump") {
+      Archive in(argv[2]);
+      const auto &fmt = in.meta().header_fmt;
+      std::printf("first_header %s\nfields %zu\nblocks %zu\n", in.meta().first_header.c_str(), fmt.n_fields(), in.nBlocks());
+      for (const auto &e : in.indexEntries()) std::printf("index %lld %u\n", static_cast<long long>(e.first), e.second);
+      CompressedBuffersSrc cbs;
+      const headers::header_fields_t first = headers::fromHeader(in.meta().first_header, fmt);
+      while (in.readBlock(cbs)) {
+        DecompressionWorkspace::decompressMiscBuffers(cbs, fmt);
+        std::printf("block %u total %u n_records %u seq %zu qual %zu\n", cbs.chunk_idx, cbs.original_size.total,
+                    cbs.original_size.n_records, cbs.seq.size(), cbs.qual.size());
+        hex("readlens", cbs.readlens);
+        hex("n_count", cbs.n_count);
+        hex("n_pos", cbs.n_pos);
+        headers::header_fields_t prev = first;
+        // headers are decoded one behind the other like decodeChunk lays them out: the string
+        // fields of `prev` keep pointing at bytes that stay
+        std::vector<char> arena(cbs.original_size.total + 1 + fmt.n_fields() * (headers::FIELDLEN_MAX + 1));
+        char *dst = arena.data();
+        for (uint32_t r = 0; r < cbs.original_size.n_records; ++r) {
+          const unsigned n = headers::decodeHeader(dst, fmt, prev, cbs.header_fields);
+          std::printf("h %.*s\n", static_cast<int>(n), dst);
+          dst += n;
+        }
+      }
+      return 0;
+    }
+  } catch (const std::exception &e) {
+    std::printf("exception: %s\n", e.what());
+    return 1;
+  }
+  std::printf("usage: archive_tool copy <in> <out> | dump <in>\n");
+  return 2;
+}

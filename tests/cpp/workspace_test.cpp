@@ -1,7 +1,9 @@
 // The reference's hot-path tests restated against the drop-in shim
 // (reference test/workspace_test.cpp:45-69 "Workspace::encodeChunk",
 //  test/fse_sequence_test.cpp:17-50, test/fse_quality_test.cpp:17-49: all round-trips).
-// Usage: workspace_test <fastq> [<fastq> ...]   (needs a GPU)
+// Beyond the reference's round trips the shim's streams are compared BYTE FOR BYTE with the CPU
+// oracle's (written to files by the Python test): cbs.seq / cbs.qual / readlens / n_count / n_pos.
+// Usage: workspace_test <fastq> <oracle stream prefix> [<fastq> <prefix> ...]   (needs a GPU)
 #include "../../fqcomp28_amd/csrc/workspace.hpp"
 
 #include <cstdio>
@@ -29,6 +31,10 @@ static CompressedBuffersSrc convertToSrcBuffers(CompressedBuffersDst &&in) {  //
   src.n_pos = std::move(in.n_pos);
   src.index.n_pos = src.n_pos.size();
   src.readlens = std::move(in.readlens);
+  src.compressed_readlens = std::move(in.compressed_readlens);
+  src.compressed_n_count = std::move(in.compressed_n_count);
+  src.compressed_n_pos = std::move(in.compressed_n_pos);
+  src.compressed_header_fields = std::move(in.compressed_header_fields);
   src.chunk_idx = in.chunk_idx;
   src.header_fields.resize(in.header_fields.size());
   for (std::size_t i = 0; i < in.header_fields.size(); ++i) {
@@ -41,7 +47,18 @@ static CompressedBuffersSrc convertToSrcBuffers(CompressedBuffersDst &&in) {  //
 
 #define CHECK(x) do { if (!(x)) { std::printf("CHECK failed: %s (%s:%d)\n", #x, __FILE__, __LINE__); return 1; } } while (0)
 
-static int encodeChunkRoundTrip(const char *path) {
+static std::vector<std::byte> fileBytes(const std::string &path) {
+  std::ifstream ifs(path, std::ios::binary);
+  std::vector<char> c((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
+  std::vector<std::byte> b(c.size());
+  std::memcpy(b.data(), c.data(), c.size());
+  return b;
+}
+template <class A, class B> static bool sameBytes(const A &a, const B &b) {
+  return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size()) == 0;
+}
+
+static int encodeChunkRoundTrip(const char *path, const std::string &oracle_prefix) {
   FastqChunk chunk_in = loadFastqFileContents(path);
   const FastqData original = chunk_in.raw_data;
   const DatasetMeta meta(chunk_in);
@@ -53,7 +70,19 @@ static int encodeChunkRoundTrip(const char *path) {
   for (int pass = 0; pass < 2; ++pass) {
     chunk_in.raw_data = original;
     cwksp.encodeChunk(chunk_in, cbs);
+    if (pass == 0) {  // fresh buffers: exactly the oracle's bytes (tables from the same chunk on both sides)
+      CHECK(sameBytes(cbs.seq, fileBytes(oracle_prefix + ".seq")));
+      CHECK(sameBytes(cbs.qual, fileBytes(oracle_prefix + ".qual")));
+      CHECK(sameBytes(cbs.readlens, fileBytes(oracle_prefix + ".readlens")));
+      CHECK(sameBytes(cbs.n_count, fileBytes(oracle_prefix + ".n_count")));
+      CHECK(sameBytes(cbs.n_pos, fileBytes(oracle_prefix + ".n_pos")));
+      CHECK(std::memcmp(chunk_in.raw_data.data(), fileBytes(oracle_prefix + ".raw_after").data(), original.size()) == 0);
+    }
   }
+  // the misc streams went through compressMiscBuffers: compressed twins within the bound, sizes recorded
+  CHECK(cbs.compressed_readlens.size() <= cbs.readlens.size() + 28 && !cbs.compressed_readlens.empty());
+  CHECK(cbs.original_size.readlens == cbs.readlens.size() && cbs.original_size.n_pos == cbs.n_pos.size());
+  CHECK(cbs.compressed_header_fields.size() == meta.header_fmt.n_fields());
   CHECK(cbs.seq.size() <= Workspace::compressBoundSequence(chunk_in.tot_reads_length));
   CHECK(cbs.n_count.size() == 2 * chunk_in.records.size() * sizeof(readlen_t));
 
@@ -78,6 +107,9 @@ static int encodeChunkRoundTrip(const char *path) {
   FastqChunk chunk_out;
   chunk_out.raw_data.assign(7, 'x');  // stale contents are dropped
   CompressedBuffersSrc src = convertToSrcBuffers(std::move(cbs));
+  // what decodeChunk gets from an archive is the compressed twins: wipe the plain copies
+  src.readlens.clear(); src.n_count.clear(); src.n_pos.clear();
+  for (auto &f : src.header_fields) f.clear();
   dwksp.decodeChunk(chunk_out, src);
   for (const auto &f : src.header_fields) {  // every stream fully consumed
     CHECK(f.index.isDifferentPos == f.isDifferentFlag.size());
@@ -120,9 +152,9 @@ static int encodeChunkRoundTrip(const char *path) {
 int main(int argc, char **argv) {
   if (fqgpu_device_count() < 1) { std::printf("no GPU: the shim has no CPU fallback\n"); return 2; }
   int bad = 0;
-  for (int i = 1; i < argc; ++i) {
+  for (int i = 1; i + 1 < argc; i += 2) {
     try {
-      bad += encodeChunkRoundTrip(argv[i]);
+      bad += encodeChunkRoundTrip(argv[i], argv[i + 1]);
     } catch (const std::exception &e) {
       std::printf("exception on %s: %s\n", argv[i], e.what());
       bad++;

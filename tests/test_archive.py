@@ -1,0 +1,185 @@
+"""The `.fqc` block container and the misc-stream coder, host side, CPU only.
+
+The product's container code (fqcomp28_amd/csrc/archive.hpp, driven through tests/cpp/archive_tool.cpp)
+is checked against oracle/fqc_archive.py -- an independent Python reading of the reference's layout
+(src/archive.h:10-17: block count, metadata, blocks, index; src/archive.cpp:57-106: field order;
+src/archive.h:20-27: 16-byte index entries sorted by chunk index on load, :85-89) -- on archives
+whose seq/qual streams are the CPU oracle's.  The misc streams' compressed bytes are the library's
+own coder's (libbsc is out of parity scope); the coder itself is tested for round trip, bound
+(src_size + 28, src/workspace.h:18), empty input and refusal of damaged input.
+"""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fqc_archive as A  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+FIXTURES = ["SRR065390_sub_1", "without_ns", "SRR065390_sub_2", "SRR065390_1_first5"]
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fqcomp28_amd as F
+    F.lib()
+    return F
+
+
+@pytest.fixture(scope="module")
+def tool(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("arc") / "archive_tool")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "archive_tool.cpp"),
+                    "-L" + os.path.join(ROOT, "fqcomp28_amd"), "-lfqgpu", "-Wl,-rpath," + os.path.join(ROOT, "fqcomp28_amd"),
+                    "-lpthread"], check=True)
+    return exe
+
+
+def split_blocks(raw, recs, n):
+    """n blocks of whole records -> [(raw, recs)] with block-relative offsets"""
+    cuts = np.linspace(0, len(recs), n + 1).astype(int)
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo = 0 if a == 0 else int(recs[a - 1]["qual_off"] + recs[a - 1]["len"] + 1)
+        hi = int(recs[b - 1]["qual_off"] + recs[b - 1]["len"] + 1)
+        r = recs[a:b].copy()
+        r["seq_off"] -= lo
+        r["qual_off"] -= lo
+        out.append((raw[lo:hi], r))
+    return out
+
+
+def oracle_archive(F, path, raw, recs, n_blocks, order=None, compress=None):
+    """archive of `raw` in n_blocks blocks, coded by the CPU oracle, written by the Python writer"""
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    octx = O.OracleCtx(sft, qft)
+    parts = split_blocks(raw, recs, n_blocks)
+    first_header = A.headers_of(raw, recs[:1])[0]
+    comp = (lambda d: F.memcompress(np.frombuffer(d, dtype=np.uint8)).tobytes()) if compress is None else compress
+    blocks, encs = [], []
+    for i, (braw, brecs) in enumerate(parts):
+        e = octx.encode(braw, brecs)
+        assert e["rc"] == 0
+        encs.append(e)
+        blocks.append(A.block_from_streams(i, braw, brecs, e, first_header, compress=comp))
+    order = list(range(n_blocks)) if order is None else order
+    A.write_archive(path, first_header, sft.tobytes(), qft.tobytes(), [blocks[i] for i in order])
+    return parts, encs, blocks, (sft, qft)
+
+
+# ---------------------------------------------------------------- misc-stream coder
+def test_memcompress_roundtrip_bound_and_edge_cases(F):
+    rng = np.random.default_rng(7)
+    cases = [np.zeros(0, np.uint8), np.arange(5, dtype=np.uint8), np.zeros(16, np.uint8), rng.integers(0, 256, 17, dtype=np.uint8),
+             np.full(100000, 150, np.uint16).view(np.uint8),          # readlens of fixed-length reads
+             np.ones(60000, np.int32).view(np.uint8),                 # "+1" read-number deltas
+             rng.integers(0, 256, 50000, dtype=np.uint8),             # incompressible -> stored
+             rng.integers(0, 3, 50001).astype(np.uint8),              # n_count-like
+             rng.integers(0, 300, 1 << 18).astype(np.uint16).view(np.uint8),
+             np.frombuffer(b"HWUSI-EAS687_61DAJ" * 2000, dtype=np.uint8)]
+    for c in cases:
+        z = F.memcompress(c)
+        assert z.size <= c.size + 28                                   # extra_csize_misc, src/workspace.h:18
+        assert (z.size == 0) == (c.size == 0)                          # src/memcompress.cpp:56-57
+        assert np.array_equal(F.memdecompress(z, c.size), c)
+    assert F.memcompress(cases[4]).size < 64 and F.memcompress(cases[5]).size < 64
+    assert F.memcompress(cases[6]).size == cases[6].size + 1
+    assert F.memcompress(cases[8]).size < 0.75 * cases[8].size
+
+
+def test_memdecompress_refuses_damaged_streams(F):
+    src = np.random.default_rng(3).integers(0, 40, 40000).astype(np.uint16).view(np.uint8)
+    z = F.memcompress(src)
+    refused = 0
+    for k in list(range(0, 40)) + list(range(40, z.size, 97)):
+        bad = z.copy()
+        bad[k] ^= 0x55
+        try:
+            out = F.memdecompress(bad, src.size)
+            assert out.size == src.size  # accepted: then it is at least a full-size output
+        except F.FqgpuError:
+            refused += 1
+    assert refused > 20
+    for cut in (1, 5, z.size // 2, z.size - 1):
+        with pytest.raises(F.FqgpuError):
+            F.memdecompress(z[:cut], src.size)
+    with pytest.raises(F.FqgpuError):
+        F.memdecompress(z, src.size + 1)
+
+
+# ---------------------------------------------------------------- container
+@pytest.mark.parametrize("name", FIXTURES)
+def test_cpp_archive_reads_and_rewrites_the_python_archive_byte_for_byte(F, tool, tmp_path, golden_dir, name):
+    raw, recs = O.load_fastq(os.path.join(golden_dir, name + ".fastq"))
+    n_blocks = 1 if len(recs) < 10 else 4
+    src = str(tmp_path / "py.fqc")
+    parts, encs, blocks, _ = oracle_archive(F, src, raw, recs, n_blocks)
+    dst = str(tmp_path / "cpp.fqc")
+    r = subprocess.run([tool, "copy", src, dst], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ("copied %d blocks, index %d bytes" % (n_blocks, 4 + 16 * n_blocks)) in r.stdout  # indexBytes(), src/archive.h:57-59
+    a, b = open(src, "rb").read(), open(dst, "rb").read()
+    assert a == b, "readBlock -> writeBlock -> writeIndex does not reproduce the file"
+    # header of the file, by hand: block count first, u16 header length, the header, the two PODs
+    first_header = A.headers_of(raw, recs[:1])[0]
+    assert struct.unpack_from("<I", b, 0)[0] == n_blocks
+    assert struct.unpack_from("<H", b, 4)[0] == len(first_header) and b[6: 6 + len(first_header)] == first_header
+    meta_end = 6 + len(first_header) + 3076 + 1081348
+    # index: last 16 * n bytes, offsets ascending from the end of the metadata, padding zero
+    ents = [struct.unpack_from("<qI4s", b, len(b) - 16 * (n_blocks - i)) for i in range(n_blocks)]
+    assert ents[0][0] == meta_end and [e[1] for e in ents] == list(range(n_blocks)) and all(e[2] == b"\0\0\0\0" for e in ents)
+
+
+def test_completion_order_and_sorted_index(F, tool, tmp_path, golden_dir):
+    """Blocks land in the file in completion order; readers see them in input order
+    (sortIndex, src/archive.h:85-89).  Every stream survives the trip."""
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_1.fastq"))
+    order = [3, 0, 4, 1, 2]
+    src = str(tmp_path / "shuffled.fqc")
+    parts, encs, blocks, (sft, qft) = oracle_archive(F, src, raw, recs, 5, order=order)
+    r = subprocess.run([tool, "dump", src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[1] == "fields 11" and lines[2] == "blocks 5"
+    idx_lines = [ln.split() for ln in lines if ln.startswith("index ")]
+    assert [int(x[2]) for x in idx_lines] == [0, 1, 2, 3, 4]                 # sorted on load
+    offs = [int(x[1]) for x in idx_lines]
+    assert sorted(offs) == [offs[i] for i in order]                          # file order = completion order
+    seen = [ln for ln in lines if ln.startswith("block ")]
+    assert [int(s.split()[1]) for s in seen] == [0, 1, 2, 3, 4]
+    # per block: sizes, the misc streams after decompressMiscBuffers, every header
+    it = iter(lines[lines.index(seen[0]):])
+    for i, ((braw, brecs), e) in enumerate(zip(parts, encs)):
+        head = next(it).split()
+        assert head[:8] == ["block", str(i), "total", str(braw.size), "n_records", str(len(brecs)), "seq", str(len(e["seq"]))]
+        assert head[8:] == ["qual", str(len(e["qual"]))]
+        for name in ("readlens", "n_count", "n_pos"):
+            p = next(it).split()
+            want = e[name].astype("<u2").tobytes()
+            assert p[0] == name and int(p[1]) == len(want) and (bytes.fromhex(p[2]) if len(p) > 2 else b"") == want
+        for h in A.headers_of(braw, brecs):
+            assert next(it) == "h " + h.decode()
+    # the C++ copy keeps every block; Python reads it back
+    dst = str(tmp_path / "copy.fqc")
+    assert subprocess.run([tool, "copy", src, dst], capture_output=True).returncode == 0
+    fh, s2, q2, blocks2, entries = A.read_archive(dst)
+    assert s2 == sft.tobytes() and q2 == qft.tobytes() and [e[1] for e in entries] == [0, 1, 2, 3, 4]
+    for b0, b1 in zip(blocks, blocks2):
+        assert (b0.total, b0.n_records, b0.readlens, b0.n_count, b0.n_pos, b0.seq, b0.qual, b0.fields) == \
+               (b1.total, b1.n_records, b1.readlens, b1.n_count, b1.n_pos, b1.seq, b1.qual, b1.fields)
+
+
+def test_truncated_archive_is_refused(F, tool, tmp_path, golden_dir):
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "without_ns.fastq"))
+    src = str(tmp_path / "a.fqc")
+    oracle_archive(F, src, raw, recs, 2)
+    data = open(src, "rb").read()
+    cut = str(tmp_path / "cut.fqc")
+    open(cut, "wb").write(data[: len(data) // 3])
+    r = subprocess.run([tool, "dump", cut], capture_output=True, text=True)
+    assert r.returncode == 1 and "exception" in r.stdout

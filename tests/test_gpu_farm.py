@@ -1,0 +1,207 @@
+"""The block farm around the hot path, on a real GPU (north_star:
+"independent FASTQ blocks farmed ... embarrassingly parallel, no collectives"):
+
+* the C++ pipeline (fqcomp28_amd/csrc/process.hpp behind tools/fqc_tool.cpp: the reference's
+  processReads / processArchiveParts, src/process.cpp:32-105) with three worker threads on device 0:
+  every block of the archive it writes carries exactly the oracle's streams, the archive reads back
+  through the independent Python container reader, and decompression restores the input file;
+* decode of `.fqc` files written by the ORACLE-side writer (BASELINE configs[4] in small: the
+  reference binary cannot be built, so the CPU oracle plays its part), completion order shuffled;
+* two FRESH processes (one per rank, gloo, both on device 0 of this box) code their b mod 2 share
+  of one job with broadcast tables: the union equals the oracle's streams.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fqc_archive as A  # noqa: E402
+import headers_oracle as HO  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+FIXTURES = ["SRR065390_sub_1", "without_ns", "SRR065390_sub_2", "SRR065390_1_first5"]
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fqcomp28_amd as F
+    if F.device_count() < 1:
+        pytest.fail("no GPU visible: the product path has no CPU fallback")
+    return F
+
+
+@pytest.fixture(scope="module")
+def tool(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("farm") / "fqc_tool")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-o", exe, os.path.join(ROOT, "tools", "fqc_tool.cpp"),
+                    "-L" + os.path.join(ROOT, "fqcomp28_amd"), "-lfqgpu", "-Wl,-rpath," + os.path.join(ROOT, "fqcomp28_amd"),
+                    "-lpthread"], check=True)
+    return exe
+
+
+def run_tool(tool, *args):
+    r = subprocess.run([tool] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def first_chunk(raw, size):
+    """what FastqReader::readNextChunk(size) returns first (src/fastq_io.cpp:23-65): the whole records of raw[:size]"""
+    recs = O.parse_fastq(raw[:size]) if size < raw.size else O.parse_fastq(raw)
+    end = int(recs[-1]["qual_off"] + recs[-1]["len"] + 1)
+    return raw[:end], recs
+
+
+def check_archive_against_oracle(F, path, raw, sample_bytes, n_workers=None):
+    """every field of every block of an archive written by the GPU farm"""
+    first_header, sft_b, qft_b, blocks, entries = A.read_archive(path)
+    sft = np.frombuffer(sft_b, dtype=O.SEQ_FT_DTYPE).copy()
+    qft = np.frombuffer(qft_b, dtype=O.QUAL_FT_DTYPE).copy()
+    # dataset analysis = oracle's calculateFreqTable on the sample chunk
+    sraw, srecs = first_chunk(raw, sample_bytes)
+    _, _, osft, oqft = O.freq_tables(sraw, srecs)
+    assert sft.tobytes() == osft.tobytes() and qft.tobytes() == oqft.tobytes()
+    assert first_header == A.headers_of(sraw, srecs[:1])[0]
+    octx = O.OracleCtx(sft, qft)
+    types, _ = HO.format_from_header(first_header)
+    at = 0
+    for i, b in enumerate(blocks):  # sorted by idx = input order: the blocks tile the input file
+        assert b.idx == i
+        braw = raw[at: at + b.total]
+        brecs = O.parse_fastq(braw)
+        assert len(brecs) == b.n_records
+        e = octx.encode(braw, brecs)
+        assert e["rc"] == 0
+        assert b.seq == e["seq"].tobytes(), "seq stream of block %d" % i
+        assert b.qual == e["qual"].tobytes(), "qual stream of block %d" % i
+        for (orig, c), want in ((b.readlens, e["readlens"]), (b.n_count, e["n_count"]), (b.n_pos, e["n_pos"])):
+            got = F.memdecompress(np.frombuffer(c, dtype=np.uint8), orig)
+            assert got.tobytes() == want.astype("<u2").tobytes()
+        _, _, streams = HO.encode_headers(A.headers_of(braw, brecs), first_header)
+        for t, parts, s in zip(types, b.fields, streams):
+            wants = [bytes(s.flags), bytes(s.content), bytes(s.lengths)] if t == HO.STRING else [bytes(s.content)]
+            for (orig, c), want in zip(parts, wants):
+                assert orig == len(want) and F.memdecompress(np.frombuffer(c, dtype=np.uint8), orig).tobytes() == want
+        at += b.total
+    assert at == raw.size
+    return blocks, entries
+
+
+def test_cpp_farm_three_workers_every_block_matches_oracle(F, tool, tmp_path):
+    raw, _ = F.synth_fastq(26 << 20, 4, seed=11)       # mixed lengths, N bases: every side stream busy
+    src = tmp_path / "in.fastq"
+    raw.tofile(src)
+    arc = tmp_path / "out.fqc"
+    rep = run_tool(tool, "c", src, arc, "-t", 3, "-R", 3, "-S", 5)
+    assert rep["raw_bytes"] == raw.size and rep["blocks"] >= 8 and sum(rep["blocks_per_worker"]) == rep["blocks"]
+    assert len(rep["blocks_per_worker"]) == 3
+    blocks, entries = check_archive_against_oracle(F, str(arc), raw, 5 << 20)
+    assert len(blocks) == rep["blocks"]
+    assert sorted(e[1] for e in entries) == list(range(len(blocks)))
+    assert sum(len(b.seq) for b in blocks) == rep["seq_bytes"] and sum(len(b.qual) for b in blocks) == rep["qual_bytes"]
+    # and back: three workers decode, the writer restores the input order
+    back = tmp_path / "back.fastq"
+    rep2 = run_tool(tool, "d", arc, back, "-t", 3)
+    assert rep2["raw_bytes"] == raw.size
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+
+
+def test_cpp_farm_accumulated_n_tables_like_the_reference(F, tool, tmp_path):
+    """--accumulate-n: a worker's CompressedBuffersDst is never cleared of n_count / n_pos
+    (src/compressed_buffers.h:58-68); the archive still decodes (pops from the end)."""
+    raw, _ = F.synth_fastq(6 << 20, 4, seed=12)
+    src = tmp_path / "in.fastq"
+    raw.tofile(src)
+    arc = tmp_path / "acc.fqc"
+    rep = run_tool(tool, "c", src, arc, "-t", 1, "-R", 1, "-S", 1, "--accumulate-n")
+    _, _, _, blocks, _ = A.read_archive(str(arc))
+    sizes = [b.n_count[0] for b in blocks]
+    assert all(b > a for a, b in zip(sizes, sizes[1:])) and sizes[-1] == 2 * sum(b.n_records for b in blocks)
+    back = tmp_path / "back.fastq"
+    run_tool(tool, "d", arc, back, "-t", 2)
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+    assert rep["blocks"] == len(blocks)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_archives_written_by_the_oracle_side_decode_on_the_gpu(F, tool, tmp_path, golden_dir, name):
+    """write (Python writer, oracle streams) -> read (C++ Archive) -> GPU decode, and the other way
+    round: GPU farm writes, Python reads, oracle decodes."""
+    from test_archive import oracle_archive
+    raw, recs = O.load_fastq(os.path.join(golden_dir, name + ".fastq"))
+    n_blocks = 1 if len(recs) < 10 else 3
+    arc = tmp_path / "oracle.fqc"
+    oracle_archive(F, str(arc), raw, recs, n_blocks, order=list(range(n_blocks))[::-1])
+    back = tmp_path / "back.fastq"
+    run_tool(tool, "d", arc, back, "-t", 2)
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+    # GPU side writes: one block, tables from the whole file = the oracle's own golden configuration
+    src = tmp_path / "in.fastq"
+    raw.tofile(src)
+    arc2 = tmp_path / "gpu.fqc"
+    run_tool(tool, "c", src, arc2, "-t", 1)
+    blocks, _ = check_archive_against_oracle(F, str(arc2), raw, 128 << 20)
+    assert len(blocks) == 1
+    first_header, sft_b, qft_b, _, _ = A.read_archive(str(arc2))
+    octx = O.OracleCtx(np.frombuffer(sft_b, dtype=O.SEQ_FT_DTYPE).copy(), np.frombuffer(qft_b, dtype=O.QUAL_FT_DTYPE).copy())
+    b = blocks[0]
+    n_count = F.memdecompress(np.frombuffer(b.n_count[1], dtype=np.uint8), b.n_count[0]).view(np.uint16)
+    n_pos = F.memdecompress(np.frombuffer(b.n_pos[1], dtype=np.uint8), b.n_pos[0]).view(np.uint16)
+    rc, out = octx.decode(np.frombuffer(b.seq, dtype=np.uint8), np.frombuffer(b.qual, dtype=np.uint8), n_count, n_pos, recs,
+                          O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+
+
+def test_config5_oracle_written_archive_mixed_lengths(F, tool, tmp_path):
+    """BASELINE configs[4] in small, on a real `.fqc`-shaped file: config-4 reads, blocks coded by the
+    oracle and written in a shuffled completion order, decoded by four GPU workers."""
+    from test_archive import oracle_archive
+    raw, n = F.synth_fastq(9 << 20, 4, seed=5)
+    recs = F.parse_fastq(raw)
+    arc = tmp_path / "cfg5.fqc"
+    order = [4, 1, 6, 0, 3, 5, 2]
+    oracle_archive(F, str(arc), raw, recs, 7, order=order)
+    back = tmp_path / "back.fastq"
+    rep = run_tool(tool, "d", arc, back, "-t", 4)
+    assert sum(rep["blocks_per_worker"]) == 7 and rep["raw_bytes"] == raw.size
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+
+
+def test_two_fresh_processes_share_one_job(F, tmp_path):
+    """N > 1 as the driver launches it: one process per rank, started before any GPU call, gloo for the
+    table broadcast and the barriers (no RCCL), block b -> rank b mod 2; here both ranks sit on
+    device 0.  The union of what the two processes wrote equals the oracle's streams of the job."""
+    out = tmp_path / "streams"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2", LOCAL_RANK="0",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "fqcomp28_amd.farm", "--mib", "12", "--block-mib", "2", "--sample-mib", "4",
+           "--device", "0", "--out", str(out)]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    rep = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][-1])
+    assert rep["world"] == 2 and rep["n_blocks"] == 6
+    assert [r["blocks"] for r in rep["ranks"]] == [[0, 2, 4], [1, 3, 5]]
+    assert rep["ranks"][0]["pid"] != rep["ranks"][1]["pid"]
+    # the same job, here: oracle tables from the first 4 MiB, oracle streams of every block
+    from fqcomp28_amd.farm import make_job
+    job = make_job(F, 12 << 20, 2 << 20)
+    sample = np.concatenate(job[:2])
+    srecs = F.parse_fastq(sample)
+    _, _, sft, qft = O.freq_tables(sample, srecs)
+    assert np.fromfile(out / "tables.seq_ft", dtype=np.uint8).tobytes() == sft.tobytes()
+    assert np.fromfile(out / "tables.qual_ft", dtype=np.uint8).tobytes() == qft.tobytes()
+    octx = O.OracleCtx(sft, qft)
+    for b, raw in enumerate(job):
+        e = octx.encode(raw, F.parse_fastq(raw))
+        for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+            got = np.fromfile(out / ("block_%d.%s" % (b, k)), dtype=e[k].dtype)
+            assert np.array_equal(got, e[k]), (b, k)

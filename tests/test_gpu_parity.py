@@ -719,6 +719,52 @@ def test_full_size_roundtrip_1gib(F):
     assert total > (1 << 30) - 16 * 400
 
 
+def _big_block_vs_oracle(F, mib):
+    """one block of `mib` MiB of config-2 reads, tables from its first 128 MiB (reference -S 128):
+    byte-compared with the oracle, or refused by both under the capacity rule (src/workspace.h:21-35)"""
+    raw, _ = F.synth_fastq(mib << 20, 2, seed=28)
+    recs = F.parse_fastq(raw)
+    srecs = recs[recs["qual_off"] + recs["len"] < (128 << 20)]
+    sft, qft = F.freq_tables(raw, srecs)
+    ctx = F.Context(sft, qft)
+    ctx.set_lanes(1)
+    b = ctx.dblock(raw, recs)
+    b.encode()
+    rc, st = b.status()
+    octx = O.OracleCtx(sft, qft)
+    e = octx.encode(raw, recs)
+    assert rc == e["rc"], (rc, e["rc"])
+    if rc == 0:
+        g = b.fetch()
+        for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+            assert np.array_equal(g[k], e[k]), k
+        b.wipe()
+        ctx.decode_dblocks([b])
+        assert b.status()[0] == 0 and np.array_equal(b.fetch_raw(), raw)
+    else:
+        assert rc == -1
+    b.close()
+    ctx.close()
+    return rc, st
+
+
+@pytest.mark.timeout(900)
+def test_one_256mib_block_bench_layout_matches_oracle(F):
+    """the block size bench.py times (-R 256: 120 M symbols per stream), against the oracle bit for bit"""
+    rc, st = _big_block_vs_oracle(F, 256)
+    assert rc == 0 and st["n_bases"] > 119_000_000
+
+
+@pytest.mark.timeout(1200)
+def test_single_1gib_block_at_the_edge_of_the_capacity_rule(F):
+    """configs[1] read literally ("single block stream", -R 1024): 480 M symbols per stream, the
+    sequence stream within a few hundred bytes of its capacity n/4 + 1024."""
+    rc, st = _big_block_vs_oracle(F, 1024)
+    assert rc in (0, -1) and st["n_bases"] > 479_000_000
+    if rc == 0:
+        assert F.bound_seq(st["n_bases"]) - st["seq_len"] < 1024
+
+
 # ---------------------------------------------------------------- extension: decode index
 @pytest.mark.parametrize("mode", [2, 4, -2])
 def test_decode_index_parallel_decode(F, mode):
@@ -779,11 +825,23 @@ def test_cpp_workspace_shim_roundtrip(golden_dir):
     exe = os.path.join(root, "tests", "cpp", "workspace_test")
     subprocess.run(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(root, "tests", "cpp", "workspace_test.cpp"),
                     "-L" + os.path.join(root, "fqcomp28_amd"), "-lfqgpu",
-                    "-Wl,-rpath," + os.path.join(root, "fqcomp28_amd")], check=True)
-    files = [os.path.join(golden_dir, f + ".fastq") for f in FIXTURES]
-    out = subprocess.run([exe] + files, capture_output=True, text=True, timeout=300)
+                    "-Wl,-rpath," + os.path.join(root, "fqcomp28_amd"), "-lpthread"], check=True)
+    import tempfile
+    args = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in FIXTURES:  # the oracle's streams of every fixture, for the byte comparison inside the C++ test
+            path = os.path.join(golden_dir, f + ".fastq")
+            raw, recs = O.load_fastq(path)
+            _, _, sft, qft = O.freq_tables(raw, recs)
+            e = O.OracleCtx(sft, qft).encode(raw, recs)
+            assert e["rc"] == 0
+            prefix = os.path.join(tmp, f)
+            for k in ("seq", "qual", "readlens", "n_count", "n_pos", "raw_after"):
+                e[k].tofile(prefix + "." + k)
+            args += [path, prefix]
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("ok ") == len(files)
+    assert out.stdout.count("ok ") == len(FIXTURES)
 
 
 # ---------------------------------------------------------------- next row: GPU FASTQ record parser

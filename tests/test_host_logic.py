@@ -118,14 +118,32 @@ WORKER = r"""
 import os, sys
 sys.path.insert(0, %r)
 import torch.distributed as dist
-from fqcomp28_amd.farm import shard_blocks, reduce_max, reduce_sum
-dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+import numpy as np
+from fqcomp28_amd.farm import shard_blocks, reduce_max, reduce_sum, broadcast_tables, gather_objects, init_dist, barrier
+from fqcomp28_amd.binding import SEQ_FT_DTYPE, QUAL_FT_DTYPE
+dist = init_dist()
+assert dist.get_backend() == "gloo"
 r, w = dist.get_rank(), dist.get_world_size()
 mine = shard_blocks(9, r, w)
 n = reduce_sum(float(len(mine)), dist)
 t = reduce_max(1.0 + r, dist)
-dist.barrier()
+barrier(dist)
 assert n == 9.0 and t == float(w), (n, t)
+# one sample's tables, broadcast as bytes from rank 0 (the others start with nothing)
+sft = qft = None
+if r == 0:
+    rng = np.random.default_rng(5)
+    sft = rng.integers(0, 256, SEQ_FT_DTYPE.itemsize, dtype=np.uint8).view(SEQ_FT_DTYPE)
+    qft = rng.integers(0, 256, QUAL_FT_DTYPE.itemsize, dtype=np.uint8).view(QUAL_FT_DTYPE)
+sft, qft = broadcast_tables(sft, qft, dist)
+want = np.random.default_rng(5)
+assert sft.tobytes() == want.integers(0, 256, SEQ_FT_DTYPE.itemsize, dtype=np.uint8).tobytes()
+assert qft.tobytes() == want.integers(0, 256, QUAL_FT_DTYPE.itemsize, dtype=np.uint8).tobytes()
+got = gather_objects({"rank": r, "blocks": mine}, dist)
+if r == 0:
+    assert sorted(b for g in got for b in g["blocks"]) == list(range(9))
+else:
+    assert got is None
 print("rank", r, "ok", mine)
 dist.destroy_process_group()
 """
