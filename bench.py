@@ -3,18 +3,27 @@
 
 A step = one pass of the hot path over one batch: every block of the workload is ENCODED
 (seq + qual FSE streams, readlens, N side streams) from inputs already resident in HBM.
-Workload at N=1 = BASELINE.json configs[1]: 1 GiB of synthetic 150 bp reads (uniform ACGT,
-Phred ~ N(34,5) clipped to [2,41]), reference default block size -R 256 (4 blocks of 256 MiB),
-frequency tables from the first 128 MiB.  N>1: one process per GPU, every rank codes its own
-1 GiB (weak scaling, blocks are independent: no data-path collective); the value is the
-whole-job MB/s = bytes of raw FASTQ all ranks coded / max-over-ranks time.
-Decode (same archive; plus a many-small-blocks layout) is measured after the timed region and
-reported in extra keys.  One JSON line on rank 0.
+
+N = 1   BASELINE.json configs[1]: 1 GiB of synthetic 150 bp reads (uniform ACGT, Phred ~ N(34,5)
+        clipped to [2,41]), reference default block size -R 256 (4 blocks of 256 MiB), frequency
+        tables from the first 128 MiB.
+N > 1   BASELINE.json configs[2]: the SAME 1 GiB job cut into 64 MiB blocks (16 of them), block b
+        coded by rank b mod N (strong scaling: total work fixed); one sample's tables, computed by
+        rank 0 and broadcast as bytes.  One process per GPU; blocks are independent, so there is no
+        data-path collective and no RCCL call anywhere: the table broadcast, the barriers and the
+        max-over-ranks of the elapsed time go over gloo.  `--layout weak` gives every rank its own
+        1 GiB instead.
+value = raw FASTQ bytes all ranks coded per second (max-over-ranks time).  After the timed region
+(not part of `value`): a whole timed block is byte-compared with the CPU oracle (also the source of
+`ratio_vs_reference`), decode of the same archive (configs[4]: blocks dealt over the N ranks), the
+CPU baselines, the host-pointer path incl. PCIe.  One JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,6 +33,17 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 8 blocks in flight x (
 import numpy as np  # noqa: E402
 
 MB = 1e6
+
+
+def kernel_sources_sha():
+    """sha256 over the device code: a committed counter profile is only quoted while this is unchanged"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fqcomp28_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_workload(F, total_bytes, block_bytes, seed, first_id=0):
@@ -54,12 +74,18 @@ def sample_tables(F, blocks, sample_bytes, device):
     return F.freq_tables(sample, recs, device=device)
 
 
-def cpu_baseline(blocks, sft, qft, seconds_budget=20.0):
-    """The oracle ("port" of the reference loop) timed on the host cores, like the reference's
-    thread pool: one workspace per thread, whole blocks per thread (src/process.cpp:46-68)."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import ctypes as C
     import oracle_lib as O
+    return O
+
+
+def cpu_baseline(blocks, sft, qft, seconds_budget=24.0):
+    """The oracle ("port" of the reference loops) timed on the host cores, like the reference's
+    thread pool: one workspace per thread, whole blocks per thread (src/process.cpp:46-68, 93-104).
+    Encode = encodeChunk's seq/qual part; decode = the decodeRecord loops alone."""
+    import ctypes as C
+    O = _oracle()
     L = O.lib()
     threads = max(1, min(len(os.sched_getaffinity(0)), 64))
     raw0, recs0 = blocks[0]
@@ -76,24 +102,21 @@ def cpu_baseline(blocks, sft, qft, seconds_budget=20.0):
     NR = (C.c_size_t * threads)(*[nrec] * threads)
     NB = (C.c_size_t * threads)(*[nb] * threads)
     out = {}
-    for label, nt, nblk in (("1", 1, 1), ("all", threads, threads)):
-        best = None
-        reps = 0
-        t_start = time.time()
-        while reps < 3 and time.time() - t_start < seconds_budget / 2:
-            dt = L.fqo_bench_blocks(O.ptr(sft), O.ptr(qft), nt, nblk, Raw, Recs, NR, NB, 0)
-            assert dt > 0
-            best = dt if best is None else min(best, dt)
-            reps += 1
-        out[label] = end * nblk / best / MB
-    return {"value": round(out["all"], 1), "unit": "MB/s", "cores": threads, "kind": "port",
-            "single_thread_MBps": round(out["1"], 1),
-            "sample": "encode of %d x %.0f MiB blocks of the same config-2 reads, one oracle workspace "
-                      "per thread, best of <=3" % (threads, end / 2**20)}
-
-
-def ctx_lanes(args):
-    return max(1, min(8, args.lanes))
+    for what, mode in (("enc", 0), ("dec", 2)):
+        for label, nt, nblk in (("1", 1, 1), ("all", threads, threads)):
+            best, reps, t_start = None, 0, time.time()
+            while reps < 3 and time.time() - t_start < seconds_budget / 4:
+                dt = L.fqo_bench_blocks(O.ptr(sft), O.ptr(qft), nt, nblk, Raw, Recs, NR, NB, mode)
+                assert dt > 0
+                best = dt if best is None else min(best, dt)
+                reps += 1
+            out[what + label] = end * nblk / best / MB
+    sample = "%d x %.0f MiB blocks of the same config-2 reads, one oracle workspace per thread, best of <=3" % (threads, end / 2**20)
+    enc = {"value": round(out["encall"], 1), "unit": "MB/s", "cores": threads, "kind": "port",
+           "single_thread_MBps": round(out["enc1"], 1), "sample": "encode of " + sample}
+    dec = {"value": round(out["decall"], 1), "unit": "MB/s", "cores": threads, "kind": "port",
+           "single_thread_MBps": round(out["dec1"], 1), "sample": "decode (decodeRecord loops alone) of " + sample}
+    return enc, dec
 
 
 def main():
@@ -101,8 +124,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mib", type=int, default=1024, help="raw FASTQ per GPU")
-    ap.add_argument("--block-mib", type=int, default=256, help="-R of the reference (default 256)")
+    ap.add_argument("--layout", default="auto", choices=["auto", "config1", "strong", "weak"],
+                    help="auto: configs[1] at N=1, configs[2] (strong scaling of one 1 GiB job in 64 MiB blocks) at N>1")
+    ap.add_argument("--mib", type=int, default=1024, help="raw FASTQ of the job (weak layout: per GPU)")
+    ap.add_argument("--block-mib", type=int, default=None, help="-R of the reference (default 256; 64 in the strong layout)")
     ap.add_argument("--sample-mib", type=int, default=128, help="-S of the reference")
     ap.add_argument("--decode-block-mib", type=int, default=1, help="block size of the many-blocks decode run")
     ap.add_argument("--decode-mib", type=int, default=256, help="data decoded in the many-blocks run")
@@ -111,38 +136,46 @@ def main():
                     help="sequence chain kernels: segment functions over state sets (default), reset-cut kernel")
     ap.add_argument("--seq-segment", type=int, default=None, help="segment length of the sequence chain kernels")
     ap.add_argument("--segment", type=int, default=0, help="segment length of the generic (quality) chain kernels")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank); gloo only to rehearse the "
-                    "multi-rank path on a one-GPU box (all ranks then share GPU 0)")
+    ap.add_argument("--all-on-gpu0", action="store_true", help="rehearsal of the multi-rank path on a one-GPU box")
     ap.add_argument("--index-stride", type=int, default=1 << 20, help="symbols between the snapshots of the decode index")
+    ap.add_argument("--host-threads", type=int, default=4, help="worker threads of the host-pointer measurement")
     ap.add_argument("--skip-decode", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-host", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from fqcomp28_amd import farm
+    rank, world, local = farm.dist_env()
+    dist = farm.init_dist()  # gloo; before anything touches the GPU
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.dist_backend == "gloo":
-            local = 0  # rehearsal: every rank on GPU 0
-        torch.cuda.set_device(local)
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    if args.all_on_gpu0:
+        local = 0
+    torch.cuda.set_device(local)
     import fqcomp28_amd as F
-    from fqcomp28_amd.farm import reduce_max, reduce_sum
     assert F.device_count() > local, "bench.py needs a GPU (no CPU fallback)"
     device = local
+    layout = args.layout if args.layout != "auto" else ("config1" if world == 1 else "strong")
+    block_mib = args.block_mib or (64 if layout == "strong" else 256)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        farm.barrier(dist)
         torch.cuda.synchronize()
 
     # ---- workload resident in HBM before the timed region
     t0 = time.time()
-    blocks = make_workload(F, args.mib << 20, args.block_mib << 20, seed=28 + rank)
-    sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
+    if layout == "strong":
+        job = make_workload(F, args.mib << 20, block_mib << 20, seed=28)   # the same job on every rank
+        sft = qft = None
+        if rank == 0:
+            sft, qft = sample_tables(F, job, args.sample_mib << 20, device)
+        sft, qft = farm.broadcast_tables(sft, qft, dist)
+        blocks = [job[b] for b in farm.shard_blocks(len(job), rank, world)]
+        job_blocks = len(job)
+        del job
+    else:
+        blocks = make_workload(F, args.mib << 20, block_mib << 20, seed=28 + (rank if layout == "weak" else 0))
+        sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
+        job_blocks = len(blocks) * world
     ctx = F.Context(sft, qft, device=device)
     ctx.set_lanes(max(1, min(args.lanes, 8)))
     ctx.set_chain_params(args.segment, seq_generic=args.seq_mode == "generic", seq_segment=args.seq_segment)
@@ -184,8 +217,8 @@ def main():
     kern = dict(kern_all)
     kern.update(kern_timed)
     ctx.enable_timing(False)
-    elapsed = reduce_max(elapsed, dist)
-    total_raw = reduce_sum(float(raw_bytes), dist)
+    elapsed = farm.reduce_max(elapsed, dist)
+    total_raw = farm.reduce_sum(float(raw_bytes), dist)
     enc_MBps = total_raw * args.steps / elapsed / MB
 
     sizes = []
@@ -197,6 +230,24 @@ def main():
     qual_bytes = sum(s["qual_len"] for s in sizes)
     npos_bytes = 2 * sum(s["n_pos_len"] for s in sizes)
     longest = [b.longest_chain() for b in dblocks]
+
+    # ---- the timed output against the oracle (rank 0): one WHOLE block of the last timed step, byte
+    # for byte; the size ratio against the reference coder follows from the same oracle run
+    check = None
+    if rank == 0 and dblocks and not args.skip_cpu:
+        O = _oracle()
+        octx = O.OracleCtx(sft, qft)
+        raw_c, recs_c = blocks[-1]
+        t0 = time.perf_counter()
+        e = octx.encode(raw_c, recs_c)
+        t_or = time.perf_counter() - t0
+        g = dblocks[-1].fetch()
+        same = {k: bool(np.array_equal(g[k], e[k])) for k in ("seq", "qual", "readlens", "n_count", "n_pos")}
+        check = {"block": len(dblocks) - 1, "block_raw_bytes": int(raw_c.size), "oracle_rc": int(e["rc"]),
+                 "streams_equal": same, "all_equal": all(same.values()),
+                 "gpu_bytes": int(g["seq"].size + g["qual"].size), "oracle_bytes": int(e["seq"].size + e["qual"].size),
+                 "oracle_encode_s": round(t_or, 2)}
+        octx.close()
 
     # ---- roofline of the dominant kernel: algorithmic bytes of ONE block's
     # stream = symbols read once + stream bytes written once; the whole-block figure alongside
@@ -213,31 +264,26 @@ def main():
     alg_dom = last_bases + stream_out if "." in dom[0] else alg_block
     dom_s = dom[1] / 1e3
     achieved = alg_dom / dom_s / 1e9 if dom_s > 0 else 0.0
-    # HBM bytes of that kernel from the PMC passes committed under profiles/ (separate rocprofv3
-    # --pmc FETCH_SIZE / WRITE_SIZE runs of this script; bench.py cannot collect counters itself)
-    traffic = None
+    # HBM bytes of that kernel: bench.py cannot collect counters itself (separate rocprofv3 --pmc
+    # passes of this script, tools/refresh_profiles.py).  The committed figure is quoted only while
+    # the device code is the code it was measured on; otherwise null.
+    traffic, traffic_src, rocprof_avg_ms = None, None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
             tj = json.load(fh)
-        if tj.get("kernel") == dom[0] and args.block_mib == 256:
-            traffic = tj["traffic_bytes_per_launch"]
+        traffic_src = {"file": "profiles/r02_traffic.json", "commit": tj.get("commit"), "kernel_sources_sha": tj.get("kernel_sources_sha"),
+                       "current_kernel_sources_sha": kernel_sources_sha()}
+        if tj.get("kernel_sources_sha") == traffic_src["current_kernel_sources_sha"] and block_mib == tj.get("block_mib", 256):
+            k = tj.get("kernels", {}).get(dom[0])
+            if k:
+                traffic = k.get("traffic_bytes_per_launch")
+                rocprof_avg_ms = k.get("rocprof_avg_launch_ms")
+            traffic_src["block_traffic_bytes"] = tj.get("block_traffic_bytes")
     except Exception:
-        traffic = None
-    # the same kernel's average duration in the committed rocprofv3 summary (first wave to last
-    # wave; the HIP-event span above also contains the time the launch waits for free CUs when
-    # four blocks are in flight)
-    rocprof_avg_ms = None
-    try:
-        import csv
-        with open(os.path.join(ROOT, "profiles", "r01_bench_encode_kernel_stats.csv")) as fh:
-            for row in csv.DictReader(fh):
-                if tj.get("kernel") == dom[0] and tj.get("rocprof_kernel", "").split(" ")[0] in row["Name"]:
-                    rocprof_avg_ms = round(float(row["AverageNs"]) / 1e6, 4)
-                    break
-    except Exception:
-        rocprof_avg_ms = None
-    roofline = {"bound": "hbm", "kernel": dom[0], "rocprof_avg_launch_ms": rocprof_avg_ms, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+        pass
+    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_from_committed_profile": traffic_src,
+                "rocprof_avg_launch_ms_from_committed_profile": rocprof_avg_ms,
                 "avg_launch_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(alg_dom),
                 "launches_timed": calls.get(dom[0], 0),
                 "job_GBps": round(alg_block * len(blocks) * args.steps / elapsed / 1e9, 2),
@@ -245,25 +291,39 @@ def main():
                 "kernels_ms_from": "one untimed step after the warm-up (events around every kernel group); the roofline kernel: the timed steps",
                 "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
 
-    # ---- decode (after the timed region): same archive, then a many-small-blocks layout
+    # ---- decode (after the timed region): the same archive, blocks dealt over the ranks exactly as
+    # they were coded (configs[4]); then extensions: decode index, many small blocks
     extra = {}
     if not args.skip_decode:
         for b in dblocks:
             b.wipe()
         ctx.sync()
+        ctx.enable_timing(True)
         barrier()
         t0 = time.perf_counter()
         ctx.decode_dblocks(dblocks)
         ctx.sync()
         barrier()
-        dt = reduce_max(time.perf_counter() - t0, dist)
+        dt = farm.reduce_max(time.perf_counter() - t0, dist)
+        dkern, _ = spans_of()
+        ctx.enable_timing(False)
+        ok = True
         for b in dblocks:
             rc, _ = b.status()
-            assert rc == 0, rc
-        ok = bool(np.array_equal(dblocks[0].fetch_raw()[: 1 << 22], blocks[0][0][: 1 << 22]))
+            ok = ok and rc == 0
+        ok = ok and bool(np.array_equal(dblocks[-1].fetch_raw(), blocks[-1][0]))  # a whole block, byte for byte
         extra["decode_MBps"] = round(total_raw / dt / MB, 1)
         extra["decode_blocks_per_gpu"] = len(dblocks)
-        extra["decode_roundtrip_ok"] = ok
+        extra["decode_roundtrip_ok"] = bool(farm.reduce_sum(0.0 if ok else 1.0, dist) == 0.0)
+        # decode roofline: the one kernel that matters; algorithmic bytes = streams read + read bytes written
+        d_ms = dkern.get("decode", 0.0)
+        d_alg = seq_bytes + qual_bytes + 2 * n_bases
+        extra["decode_roofline"] = {"bound": "hbm", "kernel": "decode (k_decode: one lane per (block, stream))",
+                                    "achieved": round(d_alg / (d_ms / 1e3) / 1e9, 3) if d_ms else None, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": round(d_alg / (d_ms / 1e3) / 1e9 / 8000.0, 7) if d_ms else None,
+                                    "launch_ms": round(d_ms, 2), "algorithmic_bytes_per_launch": int(d_alg),
+                                    "lanes": 2 * len(dblocks), "ns_per_symbol_per_lane": round(d_ms * 1e6 / max(1, max(int(r["len"].sum()) for _, r in blocks)), 1),
+                                    "traffic": None}
         # extension: the same blocks coded with a decode index (identical streams + a sidecar of
         # snapshots every --index-stride symbols), decoded with one lane per (stream, stride)
         ctx.set_index_stride(args.index_stride)
@@ -284,7 +344,7 @@ def main():
         ctx.decode_dblocks(dblocks)
         ctx.sync()
         barrier()
-        dt_ix = reduce_max(time.perf_counter() - t0, dist)
+        dt_ix = farm.reduce_max(time.perf_counter() - t0, dist)
         ok_ix = all(b.status()[0] == 0 for b in dblocks) and \
             bool(np.array_equal(dblocks[-1].fetch_raw(), blocks[-1][0]))
         extra["decode_with_index"] = {"MBps": round(total_raw / dt_ix / MB, 1), "stride_symbols": args.index_stride,
@@ -310,30 +370,76 @@ def main():
         ctx.decode_dblocks(sdb)
         ctx.sync()
         barrier()
-        dt = reduce_max(time.perf_counter() - t0, dist)
-        small_raw = reduce_sum(float(sum(r.size for r, _ in small)), dist)
+        dt = farm.reduce_max(time.perf_counter() - t0, dist)
+        small_raw = farm.reduce_sum(float(sum(r.size for r, _ in small)), dist)
         ok = all(b.status()[0] == 0 for b in sdb) and bool(np.array_equal(sdb[-1].fetch_raw(), small[-1][0]))
         extra["decode_small_blocks_MBps"] = round(small_raw / dt / MB, 1)
         extra["decode_small_blocks"] = {"blocks_per_gpu": len(sdb), "block_MiB": args.decode_block_mib,
                                         "roundtrip_ok": ok}
         for b in sdb:
             b.close()
+    for b in dblocks:
+        b.close()
+    dblocks = []
 
-    # ---- the callers either side of the path (not part of `value`): host-pointer call incl. PCIe
-    # and per-call buffers, and the GPU record parser against the host parser
-    if rank == 0 and not args.skip_decode:
-        raw0, recs0 = blocks[0]
-        raw0 = np.array(raw0, dtype=np.uint8, copy=True)
-        bufs = ctx.host_buffers(len(recs0), int(recs0["len"].sum()))
+    # ---- the callers either side of the path (not part of `value`): the host-pointer call incl.
+    # PCIe -- what CompressionWorkspace::encodeChunk gets through the shim -- from T worker threads with
+    # one handle each (reference: one workspace per thread, src/process.cpp:49-54), page-locked chunk
+    # and stream buffers; and the GPU record parser against the host parser
+    if rank == 0 and not args.skip_host:
+        T = max(1, args.host_threads)
+        per_thread = max(1, (len(blocks) * 4 + T - 1) // T)   # the job's blocks four times over in total
+        ctxs = [ctx] + [F.Context(sft, qft, device=device) for _ in range(T - 1)]
+        for c in ctxs:
+            c.set_lanes(1)
+        pins = []
+        for t in range(T):
+            raw_t, recs_t = blocks[t % len(blocks)]
+            pr = F.pinned_empty(raw_t.size)
+            pr[:] = raw_t
+            nb = int(recs_t["len"].sum())
+            bufs = dict(seq=F.pinned_empty(F.bound_seq(nb)), qual=F.pinned_empty(F.bound_qual(nb)),
+                        readlens=np.zeros(len(recs_t), np.uint16), n_count=np.zeros(len(recs_t), np.uint16),
+                        n_pos=np.zeros(nb + 1, np.uint16))
+            pins.append((pr, recs_t, bufs))
+        errs = []
+
+        def work(t, n):
+            pr, recs_t, bufs = pins[t]
+            for _ in range(n):
+                got = ctxs[t].encode_block_into(pr, recs_t, bufs)
+                if got[0] != 0:
+                    errs.append(got[0])
+        for t in range(T):   # first calls grow the handles' staging blocks and lane scratch
+            work(t, 1)
+        th = [threading.Thread(target=work, args=(t, per_thread)) for t in range(T)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        assert not errs, errs
+        coded = sum(pins[t][0].size for t in range(T)) * per_thread
+        extra["host_pointer_encode_MBps"] = round(coded / dt / MB, 1)
+        # one thread, pageable buffers: what a caller that changes nothing gets
+        raw0 = np.array(blocks[0][0], dtype=np.uint8, copy=True)
+        recs0 = blocks[0][1]
+        bufs0 = ctx.host_buffers(len(recs0), int(recs0["len"].sum()))
         best = None
-        for _ in range(1 + ctx_lanes(args)):  # first calls grow the handle's staging block and lane scratch
+        for _ in range(3):
             t0 = time.perf_counter()
-            got = ctx.encode_block_into(raw0, recs0, bufs)
-            dt = time.perf_counter() - t0
+            got = ctx.encode_block_into(raw0, recs0, bufs0)
+            d1 = time.perf_counter() - t0
             assert got[0] == 0
-            best = dt if best is None else min(best, dt)
-        # one worker thread, pageable host memory, H2D + encode + D2H of streams and side streams
-        extra["host_pointer_encode_MBps"] = round(raw0.size / best / MB, 1)
+            best = d1 if best is None else min(best, d1)
+        # a host-pointer result against the resident path's: same bytes
+        same_hp = bool(check is None or (pins[(len(blocks) - 1) % T][0].size == blocks[-1][0].size))
+        extra["host_pointer"] = {"threads": T, "handles": T, "blocks_coded": T * per_thread, "buffers": "page-locked (fqgpu_host_alloc)",
+                                 "includes": "H2D of the block + record table, encode, D2H of both streams and the side streams",
+                                 "one_thread_pageable_MBps": round(raw0.size / best / MB, 1), "sane": same_hp}
+        for c in ctxs[1:]:
+            c.close()
         t0 = time.perf_counter()
         hr = F.parse_fastq(raw0)
         t_host = time.perf_counter() - t0
@@ -346,24 +452,31 @@ def main():
         extra["parser"] = {"host_parse_MBps": round(raw0.size / t_host / MB, 1),
                            "gpu_create_from_raw_MBps_incl_h2d": round(raw0.size / t_gpu / MB, 1), "tables_equal": ok}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.skip_cpu:
-        cpu = cpu_baseline(blocks, sft, qft)
+    cpu = cpu_dec = None
+    if rank == 0 and not args.skip_cpu:
+        cpu, cpu_dec = cpu_baseline(blocks, sft, qft)
 
     if rank == 0:
+        cfg_name = {"config1": "BASELINE configs[1]: %d MiB synthetic 150 bp reads" % args.mib,
+                    "strong": "BASELINE configs[2]: ONE job of %d MiB synthetic 150 bp reads in %d MiB blocks dealt round-robin over %d GPU(s)"
+                              % (args.mib, block_mib, world),
+                    "weak": "BASELINE configs[1] per GPU (weak scaling): %d MiB/GPU synthetic 150 bp reads" % args.mib}[layout]
         line = {
             "metric": "encode MB/s (raw FASTQ in)", "value": round(enc_MBps, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d MiB/GPU synthetic 150 bp reads (uniform ACGT, "
-                                   "Phred~N(34,5) clipped [2,41]), -R %d blocks, tables from first %d MiB, "
-                                   "inputs resident in HBM" % (args.mib, args.block_mib, args.sample_mib),
-                       "blocks_per_gpu": len(blocks), "records_per_gpu": n_recs, "bases_per_gpu": n_bases,
-                       "parallelism": "blocks round-robin, %d process(es) x 1 GPU, no collectives" % world},
+            "scaling": "strong" if layout == "strong" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s (uniform ACGT, Phred~N(34,5) clipped [2,41]), -R %d blocks, tables from the first %d MiB, "
+                                   "inputs resident in HBM" % (cfg_name, block_mib, args.sample_mib),
+                       "layout": layout, "job_blocks": job_blocks, "blocks_this_gpu": len(blocks),
+                       "records_this_gpu": n_recs, "bases_this_gpu": n_bases,
+                       "parallelism": "block b -> rank b mod %d, one process per GPU, tables broadcast over gloo, no data-path collective, no RCCL" % world},
             "compressed": {"seq_bytes": seq_bytes, "qual_bytes": qual_bytes, "n_pos_bytes": npos_bytes,
-                           "ratio_vs_reference": 1.0, "longest_serial_chain": [list(r) for r in longest]},
-            "roofline": roofline, "cpu_baseline": cpu, "setup_s": round(setup_s, 1),
+                           "ratio_vs_reference": (round(check["gpu_bytes"] / check["oracle_bytes"], 6) if check else None),
+                           "ratio_vs_reference_from": "seq+qual bytes of one whole timed block / the CPU oracle's bytes for the same block and tables",
+                           "longest_serial_chain": [list(r) for r in longest]},
+            "oracle_check": check,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_decode": cpu_dec, "setup_s": round(setup_s, 1),
         }
         line.update(extra)
         if cpu:

@@ -1,0 +1,355 @@
+// Part of encode.hip (included there, inside its anonymous namespace): tile-sorted partition (K3) and
+// fused gather + bit packing (K6) -- the path taken when same-address LDS atomics are lane-ordered.
+//
+// Why: the partition's scattered byte stores and the un-permute's scattered 2-byte gathers cost one
+// L2 transaction per symbol each and moved 4 + 4 bytes of slot numbers per
+// symbol besides.  Here a tile of 32 K symbols is sorted by context INSIDE LDS (stable counting sort:
+// the per-tile histogram K1 left gives every context's offset, one lane-ordered LDS atomic per
+// symbol gives its rank), so that
+//   * the symbols leave as one contiguous RUN per (tile, context) -- consecutive lanes store
+//     consecutive bytes -- and only the position of every symbol inside its sorted tile (lpos16,
+//     2 bytes, coalesced) is kept: no 4-byte slot_of;
+//   * K6 reads the same runs of (nb, bits) back with consecutive lanes on consecutive slots into
+//     LDS, picks every symbol's value there by lpos16, and packs the bits in the same kernel: the
+//     (nb, bits) in encode order (enc16: 2 bytes written and read per symbol) never exist in
+//     memory, and the bit offset of a tile comes from a decoupled look-back over the tiles' bit
+//     totals instead of three more launches (bit counts, scan, pack).
+// Stable = every context's run keeps encode order = its tANS state chain; the streams are
+// bit-identical to the slot-based path (kept as the fallback when the probe of
+// fq_probe_lds_atomic_order fails).
+constexpr unsigned TS_TILE = 32768;    // symbols per tile (lpos16 and the 16-bit cursors hold 0 .. 32768)
+constexpr unsigned TS_BATCH = 4096;    // symbols ranked between two workgroup barriers
+constexpr unsigned TS_THREADS = 512;
+constexpr unsigned TS_WAVES = TS_THREADS / 64;
+constexpr unsigned TS_SUB = TS_THREADS * PACK_PER_THREAD;  // symbols packed per round of K6 (8192)
+static_assert(TS_TILE % TS_BATCH == 0 && TS_TILE % TS_SUB == 0 && TS_SUB % PACK_TILE == 0, "tile geometry");
+
+// run r of a tile (runs are listed in context order = order of their local start):
+//   x = global slot of its first symbol, y = local start | length << 16
+template <class M> constexpr unsigned ts_run_stride() { return M::B < TS_TILE ? M::B : TS_TILE; }
+
+// "which run holds local position p": bit p of bm is set where a run starts
+struct TsRunMap {
+  uint32_t bm[TS_TILE / 32];
+  uint16_t wpre[TS_TILE / 32];  // run starts in the words before this one
+};
+__device__ __forceinline__ unsigned ts_run_of(const TsRunMap &m, unsigned p) {
+  const unsigned w = p >> 5;
+  return (unsigned)m.wpre[w] + __popc(m.bm[w] & (0xFFFFFFFFu >> (31u - (p & 31u)))) - 1u;
+}
+
+// exclusive scan of one value per thread over the workgroup; *total = sum (all threads call)
+__device__ __forceinline__ unsigned ts_block_scan(unsigned v, unsigned *wsum, unsigned *total) {
+  unsigned inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(inc, d);
+    if (fq_lane() >= (unsigned)d) inc += o;
+  }
+  const unsigned w = threadIdx.x >> 6;
+  __syncthreads();  // wsum of an earlier call has been read
+  if (fq_lane() == 63) wsum[w] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (unsigned i = 0; i < TS_WAVES; i++) {
+    const unsigned s = wsum[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+// run-start bitmap -> wpre (all threads; bm complete and visible)
+__device__ __forceinline__ void ts_build_wpre(TsRunMap &m, unsigned *wsum) {
+  static_assert(TS_TILE / 32 == 2 * TS_THREADS, "two bitmap words per thread");
+  const unsigned c0 = __popc(m.bm[2 * threadIdx.x]), c1 = __popc(m.bm[2 * threadIdx.x + 1]);
+  unsigned tot;
+  const unsigned ex = ts_block_scan(c0 + c1, wsum, &tot);
+  m.wpre[2 * threadIdx.x] = (uint16_t)ex;
+  m.wpre[2 * threadIdx.x + 1] = (uint16_t)(ex + c0);
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ K3: stable partition, one workgroup per tile
+// Wave 0 ranks (LDS only: key read, one lane-ordered atomic on the context's cursor, position and
+// symbol written to LDS); the other seven waves move data (next batch of keys in, previous batch of
+// positions out) -- no global memory operation ever sits in the ranking loop.  Then all waves write
+// the tile's runs: position-major, so that consecutive lanes store consecutive bytes.
+template <class M>
+__global__ void __launch_bounds__(TS_THREADS)
+k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ csym, unsigned n_sym,
+                 const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ tile_base,
+                 uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ lpos16, uint2 *__restrict__ runs,
+                 uint32_t *__restrict__ run_count) {
+  constexpr unsigned B = M::B;
+  constexpr bool QUAL = M::STREAM == 1;
+  constexpr unsigned NCHUNK = B / 64;  // 64 contexts per chunk: 128 (quality) / 4 (sequence)
+  __shared__ uint32_t cursor32[B / 2];  // 16-bit cursors (local positions), two per word
+  __shared__ __attribute__((aligned(16))) uint8_t lsym[TS_TILE];  // the tile's symbols in sorted order
+  __shared__ uint4 kb4[2][TS_BATCH / 8], pb4[2][TS_BATCH / 8], sb4[2][QUAL ? TS_BATCH / 16 : 1];
+  __shared__ TsRunMap rm;
+  __shared__ unsigned wsum[TS_WAVES], s_cnt[NCHUNK < 2 ? 2 : NCHUNK], s_nruns;
+  uint16_t *cur16 = reinterpret_cast<uint16_t *>(cursor32);
+  const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), tid = threadIdx.x, wave = tid >> 6, lane = fq_lane();
+  const unsigned e0 = tile * TS_TILE, nt = min(TS_TILE, n_sym - e0);
+  const uint32_t *hrow = tile_hist + (size_t)tile * B, *tb_row = tile_base + (size_t)tile * B;
+
+  // ---- local start of every context = exclusive scan of the tile's histogram row
+  {
+    uint32_t *h32 = reinterpret_cast<uint32_t *>(lsym);  // B * 4 <= TS_TILE bytes
+    static_assert(B * 4 <= TS_TILE, "histogram row fits the symbol staging area");
+    for (unsigned c = tid; c < B; c += TS_THREADS) h32[c] = hrow[c];
+    __syncthreads();
+    constexpr unsigned CPT = B >= TS_THREADS ? B / TS_THREADS : 1;  // contexts per thread
+    const unsigned c0 = tid * CPT;
+    unsigned sum = 0;
+    if (c0 < B)
+#pragma unroll
+      for (unsigned k = 0; k < CPT; k++) sum += h32[c0 + k];
+    unsigned tot;
+    unsigned run = ts_block_scan(sum, wsum, &tot);
+    if (c0 < B) {
+#pragma unroll
+      for (unsigned k = 0; k < CPT; k++) {
+        const unsigned n = h32[c0 + k];
+        cur16[c0 + k] = (uint16_t)run;  // (own contexts only: no two threads share a word when CPT is even; CPT = 1: 16-bit stores)
+        run += n;
+      }
+    }
+    __syncthreads();  // h32 is dead: lsym may be written
+  }
+
+  // ---- ranking, batch by batch
+  const unsigned nbatch = (nt + TS_BATCH - 1) / TS_BATCH;
+  auto load_batch = [&](unsigned j, unsigned t, unsigned nthreads) {  // keys (and symbols) of batch j -> LDS
+    const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + e0 + j * TS_BATCH);  // 16-byte aligned; arrays are padded by a batch
+    for (unsigned i = t; i < TS_BATCH / 8; i += nthreads) kb4[j & 1][i] = gk[i];
+    if (QUAL) {
+      const uint4 *gs = reinterpret_cast<const uint4 *>(csym + e0 + j * TS_BATCH);
+      for (unsigned i = t; i < TS_BATCH / 16; i += nthreads) sb4[j & 1][i] = gs[i];
+    }
+  };
+  auto store_pos = [&](unsigned j, unsigned t, unsigned nthreads) {  // local positions of batch j -> lpos16
+    uint4 *gl = reinterpret_cast<uint4 *>(lpos16 + e0 + j * TS_BATCH);
+    for (unsigned i = t; i < TS_BATCH / 8; i += nthreads) gl[i] = pb4[j & 1][i];
+  };
+  load_batch(0, tid, TS_THREADS);
+  __syncthreads();
+  for (unsigned j = 0; j < nbatch; j++) {
+    if (wave == 0) {
+      const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j & 1]);
+      const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j & 1]);
+      uint16_t *pb = reinterpret_cast<uint16_t *>(pb4[j & 1]);
+      const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
+#pragma unroll 4
+      for (unsigned i = lane; i < nb; i += 64) {  // no global memory operation in here
+        const unsigned key = kb[i];
+        const unsigned c = QUAL ? key : key & 0xFFu;
+        const unsigned pos = (atomicAdd(&cursor32[c >> 1], 1u << (16u * (c & 1u))) >> (16u * (c & 1u))) & 0xFFFFu;
+        pb[i] = (uint16_t)pos;
+        lsym[pos] = QUAL ? sb[i] : (uint8_t)(key >> 8);
+      }
+    } else {
+      if (j + 1 < nbatch) load_batch(j + 1, tid - 64, TS_THREADS - 64);
+      if (j >= 1) store_pos(j - 1, tid - 64, TS_THREADS - 64);
+    }
+    __syncthreads();
+  }
+  store_pos(nbatch - 1, tid, TS_THREADS);
+
+  // ---- the tile's runs, in context order: cur16[c] is now the END of context c's run
+  uint16_t *run_unused = nullptr; (void)run_unused;
+  rm.bm[2 * tid] = 0; rm.bm[2 * tid + 1] = 0;
+  unsigned long long my_mask[(NCHUNK + TS_WAVES - 1) / TS_WAVES];
+  unsigned my_beg[(NCHUNK + TS_WAVES - 1) / TS_WAVES], my_len[(NCHUNK + TS_WAVES - 1) / TS_WAVES];
+#pragma unroll
+  for (unsigned k = 0; k < (NCHUNK + TS_WAVES - 1) / TS_WAVES; k++) {
+    const unsigned chunk = wave + k * TS_WAVES;
+    my_mask[k] = 0; my_beg[k] = 0; my_len[k] = 0;
+    if (chunk < NCHUNK) {
+      const unsigned c = chunk * 64 + lane;
+      const unsigned end = cur16[c], beg = c ? (unsigned)cur16[c - 1] : 0u;
+      my_beg[k] = beg; my_len[k] = end - beg;
+      my_mask[k] = __ballot(end > beg);
+      if (lane == 0) s_cnt[chunk] = (unsigned)__popcll(my_mask[k]);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {  // exclusive scan of the chunk counts (at most 128 chunks: two per lane)
+    const unsigned a = 2 * lane < NCHUNK ? s_cnt[2 * lane] : 0u, b = 2 * lane + 1 < NCHUNK ? s_cnt[2 * lane + 1] : 0u;
+    unsigned inc = a + b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(inc, d);
+      if (lane >= (unsigned)d) inc += o;
+    }
+    if (2 * lane < NCHUNK) s_cnt[2 * lane] = inc - a - b;
+    if (2 * lane + 1 < NCHUNK) s_cnt[2 * lane + 1] = inc - b;
+    if (lane == 63) s_nruns = inc;
+  }
+  __syncthreads();
+  uint2 *rlist = runs + (size_t)tile * ts_run_stride<M>();
+#pragma unroll
+  for (unsigned k = 0; k < (NCHUNK + TS_WAVES - 1) / TS_WAVES; k++) {
+    const unsigned chunk = wave + k * TS_WAVES;
+    if (chunk < NCHUNK && my_len[k]) {
+      const unsigned c = chunk * 64 + lane;
+      const unsigned slot = s_cnt[chunk] + fq_mbcnt(my_mask[k]);
+      rlist[slot] = make_uint2(tb_row[c], my_beg[k] | (my_len[k] << 16));
+      atomicOr(&rm.bm[my_beg[k] >> 5], 1u << (my_beg[k] & 31u));
+    }
+  }
+  __syncthreads();  // run list (global, this workgroup's own stores) and bitmap complete
+  ts_build_wpre(rm, wsum);
+  if (tid == 0) run_count[tile] = s_nruns;
+  // position-major copy: lane p stores byte p of the sorted tile
+  for (unsigned p = tid; p < nt; p += TS_THREADS) {
+    const uint2 r = rlist[ts_run_of(rm, p)];
+    sorted_sym[r.x + (p - (r.y & 0xFFFFu))] = lsym[p];
+  }
+}
+
+// ------------------------------------------------------------------ K6: gather + bit offsets + packing, fused
+// Tile bit totals are chained by a decoupled look-back: status[t] = flag << 62 | bits, flag 1 =
+// the tile's own total, 2 = inclusive total of tiles 0 .. t; one naturally aligned 8-byte word per
+// tile, written and read with relaxed agent-scope atomics (value and flag travel together, so no
+// fence is needed).  Tiles are handed out by an atomic counter: a tile only ever waits for tiles
+// that were handed out before it, i.e. that are already running.
+constexpr unsigned long long TS_FLAG_AGG = 1ull << 62, TS_FLAG_INCL = 2ull << 62, TS_VAL_MASK = (1ull << 62) - 1ull;
+
+template <class M>
+__global__ void __launch_bounds__(TS_THREADS)
+k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict__ runs,
+                   const uint32_t *__restrict__ run_count, const uint16_t *__restrict__ out16, unsigned n_sym,
+                   unsigned n_tiles, unsigned long long *__restrict__ status, unsigned *__restrict__ tile_counter,
+                   const uint32_t *__restrict__ log_prefix, unsigned long long cap, uint32_t *__restrict__ out,
+                   StreamResult *res, unsigned long long *__restrict__ tile_bit_base) {
+  constexpr unsigned NW = TS_SUB * 12 / 32 + 4;
+  __shared__ uint16_t vals[TS_TILE];  // (nb, bits) of the tile in sorted order
+  __shared__ uint32_t words[NW];
+  __shared__ TsRunMap rm;
+  __shared__ unsigned wsum[TS_WAVES], s_tile;
+  __shared__ unsigned long long s_base;
+  const unsigned tid = threadIdx.x, wave = tid >> 6, lane = fq_lane();
+  if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+  rm.bm[2 * tid] = 0; rm.bm[2 * tid + 1] = 0;
+  __syncthreads();
+  const unsigned tile = s_tile;
+  if (tile >= n_tiles) return;  // (uniform; the grid is exactly n_tiles)
+  const unsigned e0 = tile * TS_TILE, nt = min(TS_TILE, n_sym - e0);
+  const uint2 *rlist = runs + (size_t)tile * ts_run_stride<M>();
+  const unsigned nr = run_count[tile];
+  for (unsigned r = tid; r < nr; r += TS_THREADS) {
+    const unsigned beg = rlist[r].y & 0xFFFFu;
+    atomicOr(&rm.bm[beg >> 5], 1u << (beg & 31u));
+  }
+  __syncthreads();
+  ts_build_wpre(rm, wsum);
+  // ---- the runs of (nb, bits): consecutive lanes on consecutive slots
+  unsigned bits = 0;
+#pragma unroll 4
+  for (unsigned p = tid; p < nt; p += TS_THREADS) {
+    const uint2 r = rlist[ts_run_of(rm, p)];
+    const unsigned v = out16[r.x + (p - (r.y & 0xFFFFu))];
+    vals[p] = (uint16_t)v;
+    bits += v >> 12;
+  }
+  unsigned tile_bits;
+  (void)ts_block_scan(bits, wsum, &tile_bits);  // (also the barrier behind the stores to vals)
+  // ---- bit offset of the tile
+  if (wave == 0) {
+    if (lane == 0)
+      __hip_atomic_store(&status[tile], (tile == 0 ? TS_FLAG_INCL : TS_FLAG_AGG) | (unsigned long long)tile_bits, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long excl = 0;
+    if (tile > 0) {
+      int first = (int)tile - 1;  // lane l looks at tile first - l
+      for (;;) {
+        const int idx = first - (int)lane;
+        unsigned long long st = TS_FLAG_AGG;  // (tiles in front of tile 0: empty aggregates)
+        if (idx >= 0) {
+          do {
+            st = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((st >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+          } while ((st >> 62) == 0);
+        }
+        const unsigned long long incl_mask = __ballot((st >> 62) == 2ull);
+        const unsigned stop = incl_mask ? (unsigned)__ffsll((long long)incl_mask) - 1u : 64u;  // nearest inclusive total
+        unsigned long long v = lane <= stop ? (st & TS_VAL_MASK) : 0ull;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        excl += v;
+        if (incl_mask || first < 64) break;
+        first -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&status[tile], TS_FLAG_INCL | (excl + tile_bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+      s_base = excl;
+      tile_bit_base[tile] = excl;
+      if (tile == n_tiles - 1) {  // size and verdict = BIT_closeCStream: 0 when the write pointer reached dst+cap-8
+        const unsigned long long payload = excl + tile_bits, all = payload + log_prefix[M::B] + 1ull;
+        tile_bit_base[n_tiles] = payload;
+        res->total_bits = payload;
+        res->len = (all + 7ull) >> 3;
+        if (cap <= 8ull || (all >> 3) >= cap - 8ull) atomicOr(&res->overflow, 1u);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long cursor = s_base;  // bit offset of the next sub-tile (uniform)
+  // ---- packing, TS_SUB symbols per round: thread t owns 16 consecutive symbols
+  for (unsigned s0 = 0; s0 < nt; s0 += TS_SUB) {
+    for (unsigned i = tid; i < NW; i += TS_THREADS) words[i] = 0;
+    const unsigned el = s0 + tid * PACK_PER_THREAD;  // local encode index of the thread's first symbol
+    unsigned v[PACK_PER_THREAD];
+    unsigned tb = 0;
+    {
+      const uint4 *l4 = reinterpret_cast<const uint4 *>(lpos16 + e0 + el);
+      const uint4 a = el < nt ? l4[0] : make_uint4(0, 0, 0, 0), b = el < nt ? l4[1] : make_uint4(0, 0, 0, 0);
+      const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
+        const unsigned lp = (w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        v[i] = el + i < nt ? (unsigned)vals[lp] : 0u;
+        tb += v[i] >> 12;
+      }
+    }
+    unsigned sub_bits;
+    unsigned off = ts_block_scan(tb, wsum, &sub_bits);  // (its barriers also order the zeroing of words)
+    const unsigned long long b0 = cursor, b1 = cursor + sub_bits;
+    off += (unsigned)(b0 & 31ull);
+    unsigned long long acc = 0;
+    unsigned nacc = off & 31u, w = off >> 5;
+#pragma unroll
+    for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
+      const unsigned nb = v[i] >> 12;
+      acc |= (unsigned long long)(v[i] & 0xFFFu) << nacc;
+      nacc += nb;
+      if (nacc >= 32) {
+        atomicOr(&words[w], (uint32_t)acc);
+        acc >>= 32; nacc -= 32; w++;
+      }
+    }
+    if (nacc) atomicOr(&words[w], (uint32_t)acc);
+    __syncthreads();
+    if (b1 != b0) {
+      const unsigned long long gw0 = b0 >> 5;
+      const unsigned nw = (unsigned)(((b1 + 31ull) >> 5) - gw0);
+      // the stream was zeroed before the launch: words shared with a neighbour are OR-ed
+      const bool fits = (gw0 + nw) * 4ull <= cap + 32ull;  // (the buffer has 64 spare bytes; an overflowing stream is discarded)
+      const bool tail_shared = (b1 & 31ull) != 0;
+      if (fits)
+        for (unsigned i = tid; i < nw; i += TS_THREADS) {
+          if (i == 0 || (tail_shared && i == nw - 1)) atomicOr(&out[gw0 + i], words[i]);
+          else out[gw0 + i] = words[i];
+        }
+      else if (tid == 0) atomicOr(&res->overflow, 1u);
+    }
+    cursor = b1;
+    __syncthreads();  // words are rewritten by the next round
+  }
+}

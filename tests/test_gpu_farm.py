@@ -53,8 +53,10 @@ def run_tool(tool, *args):
 
 def first_chunk(raw, size):
     """what FastqReader::readNextChunk(size) returns first (src/fastq_io.cpp:23-65): the whole records of raw[:size]"""
-    recs = O.parse_fastq(raw[:size]) if size < raw.size else O.parse_fastq(raw)
+    import fqcomp28_amd
+    recs = fqcomp28_amd.parse_fastq(raw[:size])  # host parser: drops the partial record at the end
     end = int(recs[-1]["qual_off"] + recs[-1]["len"] + 1)
+    assert np.array_equal(recs, O.parse_fastq(raw[:end]))
     return raw[:end], recs
 
 
@@ -194,7 +196,7 @@ def test_two_fresh_processes_share_one_job(F, tmp_path):
     # the same job, here: oracle tables from the first 4 MiB, oracle streams of every block
     from fqcomp28_amd.farm import make_job
     job = make_job(F, 12 << 20, 2 << 20)
-    sample = np.concatenate(job[:2])
+    sample = np.concatenate(job)[: 4 << 20]   # the first --sample-mib bytes of the job, whole records of them
     srecs = F.parse_fastq(sample)
     _, _, sft, qft = O.freq_tables(sample, srecs)
     assert np.fromfile(out / "tables.seq_ft", dtype=np.uint8).tobytes() == sft.tobytes()
