@@ -222,7 +222,7 @@ static void free_lane(EncLane &l) {
   for (int s = 0; s < 2; s++) {
     EncScratch &e = l.enc[s];
     DevBuf *eb[] = {&e.slot_of, &e.keys, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
-                    &e.ctx_arrays, &e.seg_state, &e.seg_arrays, &e.seq_bdesc, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp};
+                    &e.ctx_arrays, &e.seg_state, &e.seg_arrays, &e.seq_bdesc, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp, &e.tile_runs, &e.tile_sync, &e.dbg_enc16};
     for (DevBuf *b : eb) b->release();
   }
   hipEvent_t evs[] = {l.ev_fork, l.ev_join};
@@ -394,6 +394,7 @@ extern "C" int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual
   }
   rc = fq_probe_lds_atomic_order(ctx->stream, &ctx->lds_atomics_ordered);
   if (getenv("FQGPU_NO_LDS_ATOMIC_RANK")) ctx->lds_atomics_ordered = false;  // force the ballot kernel
+  if (getenv("FQGPU_SLOT_PARTITION")) ctx->tile_sorted = false;  // the slot-based partition/gather (same bits, for comparisons)
   if (const char *e = getenv("FQGPU_SEQ_GROUP")) ctx->seq_group = (unsigned)atoi(e);  // experiments
   if (const char *e = getenv("FQGPU_SEQ_GROUP_MIN")) ctx->seq_group_min = (unsigned)atoi(e);
   if (!rc) rc = upload_tables(ctx, 0, seq_ft);
@@ -403,10 +404,17 @@ extern "C" int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual
   return FQGPU_OK;
 }
 
+#ifdef FQGPU_EXPERIMENTS
+void fq_ts_prof_dump();
+#endif
+
 extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)fqgpu_sync(ctx);
+#ifdef FQGPU_EXPERIMENTS
+  fq_ts_prof_dump();
+#endif
   free_tables(ctx->tab[0]);
   free_tables(ctx->tab[1]);
   DevBuf *bufs[] = {&ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc, &ctx->dec_chunks, &ctx->dec_recstart};

@@ -11,7 +11,7 @@ template <class M>
 __global__ void __launch_bounds__(256)
 k_index_meta(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
              const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned stride,
-             const unsigned long long *__restrict__ tile_bit_base, uint8_t *__restrict__ index) {
+             const unsigned long long *__restrict__ tile_bit_base, unsigned bit_base_unit, uint8_t *__restrict__ index) {
   const unsigned n_snap = n_sym ? (n_sym - 1) / stride : 0u;
   const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;  // 0: header, 1 .. n_snap: snapshots
   if (k == 0) {
@@ -24,7 +24,7 @@ k_index_meta(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
   if (k > n_snap) return;
   const unsigned e = k * stride;
   uint8_t *snap = index + sizeof(FqIndexHeader) + (size_t)(k - 1) * (FQ_INDEX_SNAP_HEAD + 2 * (size_t)M::B);
-  *reinterpret_cast<unsigned long long *>(snap) = tile_bit_base[e / PACK_TILE];
+  *reinterpret_cast<unsigned long long *>(snap) = tile_bit_base[e / bit_base_unit];  // stride is a multiple of both the packing tile and the sorted tile
   // symbol e - 1: record r, position p (encode order walks a record from its last position)
   const unsigned r = fq_locate(rec_start, 0, R - 1, e - 1);
   const fqgpu_rec rec = recs[r];

@@ -257,25 +257,34 @@ k_group_sum(const uint32_t *__restrict__ tile_hist, unsigned n_tiles, unsigned B
   group_sum[(size_t)g * B + c] = acc;
 }
 
-// One workgroup: per-context totals, exclusive scan over groups (in place), then the
-// context layout: padded start of every context's run, segment and work-item prefix sums.
+// Per-context totals and the exclusive scan over groups (in place): one thread per context over
+// the whole grid, eight groups' loads in flight at a time.  (Inside the single workgroup of
+// k_ctx_layout this loop was 8 contexts x n_groups dependent load/store pairs per thread: 0.17 ms
+// of a 0.45 ms layout step for the quality stream's 8192 contexts and 58 groups.)
+__global__ void __launch_bounds__(256)
+k_group_prefix(uint32_t *__restrict__ group_sum, unsigned n_groups, unsigned B, uint32_t *__restrict__ ctx_count) {
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B) return;
+  uint32_t acc = 0;
+  for (unsigned g0 = 0; g0 < n_groups; g0 += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (unsigned k = 0; k < 8; k++) v[k] = g0 + k < n_groups ? group_sum[(size_t)(g0 + k) * B + c] : 0u;
+#pragma unroll
+    for (unsigned k = 0; k < 8; k++)
+      if (g0 + k < n_groups) { group_sum[(size_t)(g0 + k) * B + c] = acc; acc += v[k]; }
+  }
+  ctx_count[c] = acc;
+}
+
+// One workgroup: the context layout from the per-context totals: padded start of every context's
+// run, segment and work-item prefix sums.
 // arrays: ctx_count[B] | ctx_start[B+1] | seg_base[B+1] | item_base[B+1]
 __global__ void __launch_bounds__(1024)
-k_ctx_layout(uint32_t *__restrict__ group_sum, unsigned n_groups, unsigned B, unsigned S,
-             uint32_t *__restrict__ arrays) {
+k_ctx_layout(unsigned B, unsigned S, uint32_t *__restrict__ arrays) {
   __shared__ unsigned part[3][1024];
   uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
            *item_base = seg_base + B + 1;
-  for (unsigned c = threadIdx.x; c < B; c += blockDim.x) {
-    uint32_t acc = 0;
-    for (unsigned g = 0; g < n_groups; g++) {
-      const uint32_t v = group_sum[(size_t)g * B + c];
-      group_sum[(size_t)g * B + c] = acc;
-      acc += v;
-    }
-    ctx_count[c] = acc;
-  }
-  __syncthreads();
   // blocked scan: thread t owns contexts [t*per, (t+1)*per)
   const unsigned per = (B + blockDim.x - 1) / blockDim.x;
   const unsigned c0 = threadIdx.x * per, c1 = min(c0 + per, B);

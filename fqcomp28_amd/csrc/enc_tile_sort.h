@@ -18,11 +18,21 @@
 // bit-identical to the slot-based path (kept as the fallback when the probe of
 // fq_probe_lds_atomic_order fails).
 constexpr unsigned TS_TILE = 32768;    // symbols per tile (lpos16 and the 16-bit cursors hold 0 .. 32768)
-constexpr unsigned TS_BATCH = 4096;    // symbols ranked between two workgroup barriers
-constexpr unsigned TS_THREADS = 512;
+constexpr unsigned TS_BATCH = 2048;    // symbols ranked between two workgroup barriers (K3: 74 KB of LDS, two workgroups per CU)
+constexpr unsigned TS_THREADS = 512;   // K3
 constexpr unsigned TS_WAVES = TS_THREADS / 64;
-constexpr unsigned TS_SUB = TS_THREADS * PACK_PER_THREAD;  // symbols packed per round of K6 (8192)
+constexpr unsigned TS_GP_THREADS = 256;  // K6: 76 KB of LDS, two workgroups per CU
+constexpr unsigned TS_SUB = TS_GP_THREADS * PACK_PER_THREAD;  // symbols packed per round of K6 (4096)
 static_assert(TS_TILE % TS_BATCH == 0 && TS_TILE % TS_SUB == 0 && TS_SUB % PACK_TILE == 0, "tile geometry");
+
+// phase timing of the two kernels (experiments build only): g_ts_prof[8 * kernel + phase] += wall clock ticks of workgroup thread 0
+#ifdef FQGPU_EXPERIMENTS
+#define TS_PROF_DECL unsigned long long ts_t_ = wall_clock64();
+#define TS_PROF(slot) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_ts_prof[slot], n_ - ts_t_); ts_t_ = n_; } } while (0)
+#else
+#define TS_PROF_DECL
+#define TS_PROF(slot) do { } while (0)
+#endif
 
 // run r of a tile (runs are listed in context order = order of their local start):
 //   x = global slot of its first symbol, y = local start | length << 16
@@ -38,7 +48,8 @@ __device__ __forceinline__ unsigned ts_run_of(const TsRunMap &m, unsigned p) {
   return (unsigned)m.wpre[w] + __popc(m.bm[w] & (0xFFFFFFFFu >> (31u - (p & 31u)))) - 1u;
 }
 
-// exclusive scan of one value per thread over the workgroup; *total = sum (all threads call)
+// exclusive scan of one value per thread over the workgroup of NT threads; *total = sum (all threads call)
+template <unsigned NT>
 __device__ __forceinline__ unsigned ts_block_scan(unsigned v, unsigned *wsum, unsigned *total) {
   unsigned inc = v;
 #pragma unroll
@@ -52,7 +63,7 @@ __device__ __forceinline__ unsigned ts_block_scan(unsigned v, unsigned *wsum, un
   __syncthreads();
   unsigned base = 0, tot = 0;
 #pragma unroll
-  for (unsigned i = 0; i < TS_WAVES; i++) {
+  for (unsigned i = 0; i < NT / 64; i++) {
     const unsigned s = wsum[i];
     if (i < w) base += s;
     tot += s;
@@ -62,20 +73,28 @@ __device__ __forceinline__ unsigned ts_block_scan(unsigned v, unsigned *wsum, un
 }
 
 // run-start bitmap -> wpre (all threads; bm complete and visible)
+template <unsigned NT>
 __device__ __forceinline__ void ts_build_wpre(TsRunMap &m, unsigned *wsum) {
-  static_assert(TS_TILE / 32 == 2 * TS_THREADS, "two bitmap words per thread");
-  const unsigned c0 = __popc(m.bm[2 * threadIdx.x]), c1 = __popc(m.bm[2 * threadIdx.x + 1]);
+  constexpr unsigned WPT = TS_TILE / 32 / NT;  // bitmap words per thread: 2 or 4
+  unsigned c[WPT], sum = 0;
+#pragma unroll
+  for (unsigned k = 0; k < WPT; k++) { c[k] = __popc(m.bm[WPT * threadIdx.x + k]); sum += c[k]; }
   unsigned tot;
-  const unsigned ex = ts_block_scan(c0 + c1, wsum, &tot);
-  m.wpre[2 * threadIdx.x] = (uint16_t)ex;
-  m.wpre[2 * threadIdx.x + 1] = (uint16_t)(ex + c0);
+  unsigned ex = ts_block_scan<NT>(sum, wsum, &tot);
+#pragma unroll
+  for (unsigned k = 0; k < WPT; k++) { m.wpre[WPT * threadIdx.x + k] = (uint16_t)ex; ex += c[k]; }
   __syncthreads();
+}
+template <unsigned NT>
+__device__ __forceinline__ void ts_clear_bitmap(TsRunMap &m) {
+#pragma unroll
+  for (unsigned k = 0; k < TS_TILE / 32 / NT; k++) m.bm[TS_TILE / 32 / NT * threadIdx.x + k] = 0;
 }
 
 // ------------------------------------------------------------------ K3: stable partition, one workgroup per tile
-// Wave 0 ranks (LDS only: key read, one lane-ordered atomic on the context's cursor, position and
-// symbol written to LDS); the other seven waves move data (next batch of keys in, previous batch of
-// positions out) -- no global memory operation ever sits in the ranking loop.  Then all waves write
+// Wave 0 ranks (key read, one lane-ordered atomic on the context's cursor, symbol written to its sorted
+// place in LDS, position stored to lpos16 -- stores only, nothing in the loop ever waits for global
+// memory); the other seven waves bring in the next batch of keys.  Then all waves write
 // the tile's runs: position-major, so that consecutive lanes store consecutive bytes.
 template <class M>
 __global__ void __launch_bounds__(TS_THREADS)
@@ -87,14 +106,16 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   constexpr bool QUAL = M::STREAM == 1;
   constexpr unsigned NCHUNK = B / 64;  // 64 contexts per chunk: 128 (quality) / 4 (sequence)
   __shared__ uint32_t cursor32[B / 2];  // 16-bit cursors (local positions), two per word
-  __shared__ __attribute__((aligned(16))) uint8_t lsym[TS_TILE];  // the tile's symbols in sorted order
-  __shared__ uint4 kb4[2][TS_BATCH / 8], pb4[2][TS_BATCH / 8], sb4[2][QUAL ? TS_BATCH / 16 : 1];
+  __shared__ __attribute__((aligned(16))) uint8_t lsym[TS_TILE + 64];  // the tile's symbols in sorted order (+ a dump for idle lanes)
+  __shared__ uint4 kb4[2][TS_BATCH / 8], sb4[2][QUAL ? TS_BATCH / 16 : 1];
   __shared__ TsRunMap rm;
   __shared__ unsigned wsum[TS_WAVES], s_cnt[NCHUNK < 2 ? 2 : NCHUNK], s_nruns;
   uint16_t *cur16 = reinterpret_cast<uint16_t *>(cursor32);
   const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), tid = threadIdx.x, wave = tid >> 6, lane = fq_lane();
   const unsigned e0 = tile * TS_TILE, nt = min(TS_TILE, n_sym - e0);
   const uint32_t *hrow = tile_hist + (size_t)tile * B, *tb_row = tile_base + (size_t)tile * B;
+  TS_PROF_DECL
+  constexpr unsigned PS = QUAL ? 0 : 8; (void)PS;
 
   // ---- local start of every context = exclusive scan of the tile's histogram row
   {
@@ -109,7 +130,7 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
 #pragma unroll
       for (unsigned k = 0; k < CPT; k++) sum += h32[c0 + k];
     unsigned tot;
-    unsigned run = ts_block_scan(sum, wsum, &tot);
+    unsigned run = ts_block_scan<TS_THREADS>(sum, wsum, &tot);
     if (c0 < B) {
 #pragma unroll
       for (unsigned k = 0; k < CPT; k++) {
@@ -121,6 +142,7 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
     __syncthreads();  // h32 is dead: lsym may be written
   }
 
+  TS_PROF(PS + 0);
   // ---- ranking, batch by batch
   const unsigned nbatch = (nt + TS_BATCH - 1) / TS_BATCH;
   auto load_batch = [&](unsigned j, unsigned t, unsigned nthreads) {  // keys (and symbols) of batch j -> LDS
@@ -131,37 +153,65 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
       for (unsigned i = t; i < TS_BATCH / 16; i += nthreads) sb4[j & 1][i] = gs[i];
     }
   };
-  auto store_pos = [&](unsigned j, unsigned t, unsigned nthreads) {  // local positions of batch j -> lpos16
-    uint4 *gl = reinterpret_cast<uint4 *>(lpos16 + e0 + j * TS_BATCH);
-    for (unsigned i = t; i < TS_BATCH / 8; i += nthreads) gl[i] = pb4[j & 1][i];
-  };
+  // Barrier of the batch loop: LDS traffic only.  __syncthreads() also drains vmcnt, i.e. the ranking
+  // wave would wait at every barrier for its position stores (fire and forget) to reach memory; the
+  // loading waves' data dependences (global load -> LDS store) already cover their loads.
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   load_batch(0, tid, TS_THREADS);
   __syncthreads();
   for (unsigned j = 0; j < nbatch; j++) {
     if (wave == 0) {
       const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j & 1]);
       const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j & 1]);
-      uint16_t *pb = reinterpret_cast<uint16_t *>(pb4[j & 1]);
+      uint16_t *gpos = lpos16 + e0 + j * TS_BATCH;  // the ranking wave stores the positions itself: 128 contiguous bytes per instruction
       const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
-#pragma unroll 4
-      for (unsigned i = lane; i < nb; i += 64) {  // no global memory operation in here
-        const unsigned key = kb[i];
-        const unsigned c = QUAL ? key : key & 0xFFu;
-        const unsigned pos = (atomicAdd(&cursor32[c >> 1], 1u << (16u * (c & 1u))) >> (16u * (c & 1u))) & 0xFFFFu;
-        pb[i] = (uint16_t)pos;
-        lsym[pos] = QUAL ? sb[i] : (uint8_t)(key >> 8);
+      // Wave-uniform trip count with the bound checked inside: with a per-lane trip count the
+      // compiler's unrolling lets low lanes run ahead of high lanes by a whole group of iterations,
+      // and the rank is only right if iteration k of every lane precedes iteration k + 1 of any lane.
+      // Software-pipelined by hand, TS_GROUP iterations at a time: all key reads, then all atomics
+      // (the LDS executes them in program order), then all stores -- three LDS round trips per group
+      // instead of three per iteration: the loop is a pure latency chain and ONE wave ranks a tile.
+      // Branch-free: a lane beyond the batch adds 0 to cursor word 0 and stores into the spare bytes
+      // behind the tile -- behind a branch hipcc waits for every atomic's return value before it
+      // issues the next one (s_waitcnt lgkmcnt(0) in each arm), which is the whole latency again.
+      constexpr unsigned G = 8;
+#ifdef FQGPU_EXPERIMENTS
+      const unsigned long long tr0 = wall_clock64();
+#endif
+      for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // no global memory operation in here
+        unsigned key[G], pos[G], sy[G];
+#pragma unroll
+        for (unsigned g = 0; g < G; g++) {
+          const unsigned i = cb + 64 * g + lane;  // < TS_BATCH: the buffers hold a whole batch
+          key[g] = kb[i];
+          sy[g] = QUAL ? (unsigned)sb[i] : key[g] >> 8;
+        }
+#pragma unroll
+        for (unsigned g = 0; g < G; g++) {
+          const bool on = cb + 64 * g + lane < nb;
+          const unsigned c = on ? (QUAL ? key[g] : key[g] & 0xFFu) : 0u;
+          pos[g] = (atomicAdd(&cursor32[c >> 1], on ? 1u << (16u * (c & 1u)) : 0u) >> (16u * (c & 1u))) & 0xFFFFu;
+        }
+#pragma unroll
+        for (unsigned g = 0; g < G; g++) {
+          const unsigned i = cb + 64 * g + lane;
+          gpos[i] = (uint16_t)pos[g];  // (beyond the batch: garbage that lands behind the tile's part of lpos16)
+          lsym[i < nb ? pos[g] : TS_TILE + lane] = (uint8_t)sy[g];
+        }
       }
+#ifdef FQGPU_EXPERIMENTS
+      if (lane == 0) atomicAdd(&g_ts_prof[PS + 4], wall_clock64() - tr0);
+#endif
     } else {
       if (j + 1 < nbatch) load_batch(j + 1, tid - 64, TS_THREADS - 64);
-      if (j >= 1) store_pos(j - 1, tid - 64, TS_THREADS - 64);
     }
-    __syncthreads();
+    lds_barrier();
   }
-  store_pos(nbatch - 1, tid, TS_THREADS);
+  TS_PROF(PS + 1);
 
   // ---- the tile's runs, in context order: cur16[c] is now the END of context c's run
   uint16_t *run_unused = nullptr; (void)run_unused;
-  rm.bm[2 * tid] = 0; rm.bm[2 * tid + 1] = 0;
+  ts_clear_bitmap<TS_THREADS>(rm);
   unsigned long long my_mask[(NCHUNK + TS_WAVES - 1) / TS_WAVES];
   unsigned my_beg[(NCHUNK + TS_WAVES - 1) / TS_WAVES], my_len[(NCHUNK + TS_WAVES - 1) / TS_WAVES];
 #pragma unroll
@@ -202,13 +252,17 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
     }
   }
   __syncthreads();  // run list (global, this workgroup's own stores) and bitmap complete
-  ts_build_wpre(rm, wsum);
+  ts_build_wpre<TS_THREADS>(rm, wsum);
   if (tid == 0) run_count[tile] = s_nruns;
+  TS_PROF(PS + 2);
   // position-major copy: lane p stores byte p of the sorted tile
+#pragma unroll 8
   for (unsigned p = tid; p < nt; p += TS_THREADS) {
     const uint2 r = rlist[ts_run_of(rm, p)];
     sorted_sym[r.x + (p - (r.y & 0xFFFFu))] = lsym[p];
   }
+  __syncthreads();
+  TS_PROF(PS + 3);
 }
 
 // ------------------------------------------------------------------ K6: gather + bit offsets + packing, fused
@@ -220,7 +274,7 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
 constexpr unsigned long long TS_FLAG_AGG = 1ull << 62, TS_FLAG_INCL = 2ull << 62, TS_VAL_MASK = (1ull << 62) - 1ull;
 
 template <class M>
-__global__ void __launch_bounds__(TS_THREADS)
+__global__ void __launch_bounds__(TS_GP_THREADS)
 k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict__ runs,
                    const uint32_t *__restrict__ run_count, const uint16_t *__restrict__ out16, unsigned n_sym,
                    unsigned n_tiles, unsigned long long *__restrict__ status, unsigned *__restrict__ tile_counter,
@@ -230,34 +284,52 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
   __shared__ uint16_t vals[TS_TILE];  // (nb, bits) of the tile in sorted order
   __shared__ uint32_t words[NW];
   __shared__ TsRunMap rm;
-  __shared__ unsigned wsum[TS_WAVES], s_tile;
+  __shared__ unsigned wsum[TS_GP_THREADS / 64], s_tile;
   __shared__ unsigned long long s_base;
   const unsigned tid = threadIdx.x, wave = tid >> 6, lane = fq_lane();
   if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
-  rm.bm[2 * tid] = 0; rm.bm[2 * tid + 1] = 0;
+  ts_clear_bitmap<TS_GP_THREADS>(rm);
   __syncthreads();
   const unsigned tile = s_tile;
   if (tile >= n_tiles) return;  // (uniform; the grid is exactly n_tiles)
+  TS_PROF_DECL
+  constexpr unsigned PS = M::STREAM == 1 ? 16 : 24; (void)PS;
   const unsigned e0 = tile * TS_TILE, nt = min(TS_TILE, n_sym - e0);
   const uint2 *rlist = runs + (size_t)tile * ts_run_stride<M>();
   const unsigned nr = run_count[tile];
-  for (unsigned r = tid; r < nr; r += TS_THREADS) {
-    const unsigned beg = rlist[r].y & 0xFFFFu;
+  // "global slot of local position p" = p + gd[run of p]; the deltas of the first NW runs sit in LDS
+  // (the packing buffer is idle until the tile's values are in), later runs are read from the list
+  uint32_t *gd = words;
+  for (unsigned r = tid; r < nr; r += TS_GP_THREADS) {
+    const uint2 e = rlist[r];
+    const unsigned beg = e.y & 0xFFFFu;
+    if (r < NW) gd[r] = e.x - beg;
     atomicOr(&rm.bm[beg >> 5], 1u << (beg & 31u));
   }
   __syncthreads();
-  ts_build_wpre(rm, wsum);
+  ts_build_wpre<TS_GP_THREADS>(rm, wsum);
+  TS_PROF(PS + 0);
   // ---- the runs of (nb, bits): consecutive lanes on consecutive slots
   unsigned bits = 0;
-#pragma unroll 4
-  for (unsigned p = tid; p < nt; p += TS_THREADS) {
-    const uint2 r = rlist[ts_run_of(rm, p)];
-    const unsigned v = out16[r.x + (p - (r.y & 0xFFFFu))];
-    vals[p] = (uint16_t)v;
-    bits += v >> 12;
+  if (nr <= NW) {  // (uniform) every lookup stays in LDS: the loads of sixteen positions per thread are in flight together
+#pragma unroll 16
+    for (unsigned p = tid; p < nt; p += TS_GP_THREADS) {
+      const unsigned v = out16[p + gd[ts_run_of(rm, p)]];
+      vals[p] = (uint16_t)v;
+      bits += v >> 12;
+    }
+  } else {
+#pragma unroll 8
+    for (unsigned p = tid; p < nt; p += TS_GP_THREADS) {
+      const uint2 r = rlist[ts_run_of(rm, p)];
+      const unsigned v = out16[r.x + (p - (r.y & 0xFFFFu))];
+      vals[p] = (uint16_t)v;
+      bits += v >> 12;
+    }
   }
   unsigned tile_bits;
-  (void)ts_block_scan(bits, wsum, &tile_bits);  // (also the barrier behind the stores to vals)
+  (void)ts_block_scan<TS_GP_THREADS>(bits, wsum, &tile_bits);  // (also the barrier behind the stores to vals)
+  TS_PROF(PS + 1);
   // ---- bit offset of the tile
   if (wave == 0) {
     if (lane == 0)
@@ -300,16 +372,23 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
     }
   }
   __syncthreads();
+  TS_PROF(PS + 2);
   unsigned long long cursor = s_base;  // bit offset of the next sub-tile (uniform)
   // ---- packing, TS_SUB symbols per round: thread t owns 16 consecutive symbols
+  // (the positions of the next round are requested before the current one is packed)
+  const uint4 *lp4 = reinterpret_cast<const uint4 *>(lpos16 + e0 + tid * PACK_PER_THREAD);
+  uint4 na = tid * PACK_PER_THREAD < nt ? lp4[0] : make_uint4(0, 0, 0, 0), nb4 = tid * PACK_PER_THREAD < nt ? lp4[1] : make_uint4(0, 0, 0, 0);
   for (unsigned s0 = 0; s0 < nt; s0 += TS_SUB) {
-    for (unsigned i = tid; i < NW; i += TS_THREADS) words[i] = 0;
+    for (unsigned i = tid; i < NW; i += TS_GP_THREADS) words[i] = 0;
     const unsigned el = s0 + tid * PACK_PER_THREAD;  // local encode index of the thread's first symbol
     unsigned v[PACK_PER_THREAD];
     unsigned tb = 0;
     {
-      const uint4 *l4 = reinterpret_cast<const uint4 *>(lpos16 + e0 + el);
-      const uint4 a = el < nt ? l4[0] : make_uint4(0, 0, 0, 0), b = el < nt ? l4[1] : make_uint4(0, 0, 0, 0);
+      const uint4 a = na, b = nb4;
+      if (el + TS_SUB < nt) {
+        const uint4 *n4 = lp4 + (s0 + TS_SUB) / 8;
+        na = n4[0]; nb4 = n4[1];
+      }
       const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
       for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
@@ -319,7 +398,7 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
       }
     }
     unsigned sub_bits;
-    unsigned off = ts_block_scan(tb, wsum, &sub_bits);  // (its barriers also order the zeroing of words)
+    unsigned off = ts_block_scan<TS_GP_THREADS>(tb, wsum, &sub_bits);  // (its barriers also order the zeroing of words)
     const unsigned long long b0 = cursor, b1 = cursor + sub_bits;
     off += (unsigned)(b0 & 31ull);
     unsigned long long acc = 0;
@@ -343,7 +422,7 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
       const bool fits = (gw0 + nw) * 4ull <= cap + 32ull;  // (the buffer has 64 spare bytes; an overflowing stream is discarded)
       const bool tail_shared = (b1 & 31ull) != 0;
       if (fits)
-        for (unsigned i = tid; i < nw; i += TS_THREADS) {
+        for (unsigned i = tid; i < nw; i += TS_GP_THREADS) {
           if (i == 0 || (tail_shared && i == nw - 1)) atomicOr(&out[gw0 + i], words[i]);
           else out[gw0 + i] = words[i];
         }
@@ -352,4 +431,5 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
     cursor = b1;
     __syncthreads();  // words are rewritten by the next round
   }
+  TS_PROF(PS + 3);
 }

@@ -31,8 +31,21 @@
 //   K7 epilogue              : state flush + end mark + size/overflow
 #include "fqgpu_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+
+#ifdef FQGPU_EXPERIMENTS
+__device__ unsigned long long g_ts_prof[32];
+void fq_ts_prof_dump() {
+  unsigned long long h[32];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts_prof), sizeof(h)) != hipSuccess) return;
+  const char *names[4] = {"partition<Qual>", "partition<Seq>", "gather_pack<Qual>", "gather_pack<Seq>"};
+  for (int k = 0; k < 4; k++)
+    fprintf(stderr, "ts_prof %-18s phase ticks (100 MHz, summed over workgroups): %llu %llu %llu %llu | ranker alone %llu\n", names[k], h[8 * k], h[8 * k + 1],
+            h[8 * k + 2], h[8 * k + 3], h[8 * k + 4]);
+}
+#endif
 
 namespace {
 
@@ -54,6 +67,7 @@ template <class M> constexpr unsigned tile_size() { return M::STREAM == 0 ? TILE
 #include "enc_seq_batch.h"
 #include "enc_index.h"
 #include "enc_pack.h"
+#include "enc_tile_sort.h"
 
 // ------------------------------------------------------------------ host orchestration
 #define FQ_SPAN_BEGIN(name) fq_timer_span_begin(ctx, name, st)
@@ -91,7 +105,11 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   constexpr unsigned B = M::B;
   const unsigned n_sym = (unsigned)b->n_bases;
   const unsigned R = (unsigned)b->n_recs;
-  const unsigned T = tile_size<M>();
+  const bool serial_seq = M::STREAM == 0 && !ctx->seq_generic;
+  // tile-sorted partition + fused gather/pack: whenever the rank may come from lane-ordered LDS atomics
+  // (the generic sequence mode keeps the slot-based kernels: it exists for comparisons only)
+  const bool tile_path = ctx->lds_atomics_ordered && ctx->tile_sorted && (M::STREAM == 1 || serial_seq);
+  const unsigned T = tile_path ? TS_TILE : tile_size<M>();
   // segment length of the generic chain kernels: whole 1024-symbol blocks
   // Default segment: 4096 symbols; shorter for small blocks, which are chains of short,
   // latency-bound kernels (a lane of the walk/emit kernels walks one segment): 16 MiB blocks
@@ -104,7 +122,6 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   const size_t padded = (size_t)n_sym + (size_t)CTX_PAD * B + 64;
   const unsigned max_items = (unsigned)((size_t)n_sym / ((size_t)S * 64) + B + 1);
   StreamResult *res = &b->result->s[M::STREAM];
-  const bool serial_seq = M::STREAM == 0 && !ctx->seq_generic;
 
   int rc;
   unsigned dbg_mask = fq_debug_skip();
@@ -142,6 +159,11 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if (serial_seq && (rc = sc.seq_bdesc.reserve((size_t)(n_ptiles + 1) * SeqModel::B * 6 + 64))) return rc;
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
   if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
+  const size_t sync_counter_off = (size_t)n_tiles * 8, sync_runcount_off = sync_counter_off + 16;
+  if (tile_path) {
+    if ((rc = sc.tile_runs.reserve((size_t)n_tiles * ts_run_stride<M>() * sizeof(uint2)))) return rc;
+    if ((rc = sc.tile_sync.reserve(sync_runcount_off + (size_t)n_tiles * 4))) return rc;
+  }
 
   uint16_t *ckey = sc.keys.as<uint16_t>();
   uint8_t *csym = reinterpret_cast<uint8_t *>(ckey + n_pad);
@@ -165,8 +187,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");  dbg_off = (dbg_mask & 2u) != 0;
   if (!dbg_off) hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
-  if (!dbg_off) hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, sc.group_sum.as<uint32_t>(), n_groups,
-                     B, S, arrays);
+  if (!dbg_off) hipLaunchKernelGGL(k_group_prefix, dim3((B + 255) / 256), dim3(256), 0, st, sc.group_sum.as<uint32_t>(), n_groups, B, arrays);
+  if (!dbg_off) hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, B, S, arrays);
   if (!dbg_off) hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B,
                      sc.tile_base.as<uint32_t>());
@@ -176,7 +198,15 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   bd.start = sc.seq_bdesc.as<uint32_t>();
   bd.pre = reinterpret_cast<uint16_t *>(bd.start + (size_t)(n_ptiles + 1) * SeqModel::B);
   uint16_t *lpos16 = reinterpret_cast<uint16_t *>(sc.slot_of.as<uint32_t>());  // the sequence stream has no slot_of
-  if (!dbg_off && serial_seq) {
+  uint8_t *sync_base = sc.tile_sync.as<uint8_t>();
+  unsigned long long *ts_status = reinterpret_cast<unsigned long long *>(sync_base);
+  unsigned *ts_counter = reinterpret_cast<unsigned *>(sync_base + sync_counter_off);
+  uint32_t *ts_run_count = reinterpret_cast<uint32_t *>(sync_base + sync_runcount_off);
+  if (tile_path) {
+    if (!dbg_off)
+      hipLaunchKernelGGL(k_tile_partition<M>, dim3(n_tiles), dim3(TS_THREADS), 0, st, ckey, csym, n_sym, sc.tile_hist.as<uint32_t>(),
+                         sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), lpos16, sc.tile_runs.as<uint2>(), ts_run_count);
+  } else if (!dbg_off && serial_seq) {
     if (ctx->lds_atomics_ordered)
       hipLaunchKernelGGL(k_scatter_seq<true>, dim3(n_tiles), dim3(64), 0, st, ckey, n_sym, T, sc.tile_base.as<uint32_t>(),
                          sc.sorted_sym.as<uint8_t>(), lpos16, bd, fq_debug_no_sym(0));
@@ -273,6 +303,18 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                        sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, sa, res);
   }
   FQ_SPAN_END();
+  if (tile_path) {
+    // the stream starts from zeros (words shared by two tiles are OR-ed into), the look-back from clean flags
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.gatherpack" : "seq.gatherpack");  dbg_off = (dbg_mask & 16u) != 0;
+    if (!dbg_off) {
+      FQ_HIP(hipMemsetAsync(out_dev, 0, cap + 64, st));
+      FQ_HIP(hipMemsetAsync(sync_base, 0, sync_counter_off + 16, st));
+      hipLaunchKernelGGL(k_tile_gather_pack<M>, dim3(n_tiles), dim3(TS_GP_THREADS), 0, st, lpos16, sc.tile_runs.as<uint2>(), ts_run_count,
+                         sc.out16.as<uint16_t>(), n_sym, n_tiles, ts_status, ts_counter, tab.log_prefix, (unsigned long long)cap,
+                         reinterpret_cast<uint32_t *>(out_dev), res, sc.tile_bit_base.as<unsigned long long>());
+    }
+    FQ_SPAN_END();
+  } else {
   FQ_SPAN_BEGIN(M::STREAM ? "qual.bitcount" : "seq.bitcount");  dbg_off = (dbg_mask & 16u) != 0;
   if (!dbg_off && serial_seq)
     hipLaunchKernelGGL(k_bitcount_seq, dim3((n_sym + SEQ_BATCH - 1) / SEQ_BATCH), dim3(PACK_THREADS), 0, st, lpos16, bd, sc.out16.as<uint16_t>(), n_sym,
@@ -290,6 +332,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if (!dbg_off) hipLaunchKernelGGL(k_pack, dim3(n_ptiles), dim3(PACK_THREADS), 0, st, enc16, n_sym,
                      sc.tile_bit_base.as<unsigned long long>(), reinterpret_cast<uint32_t *>(out_dev), res);
   FQ_SPAN_END();
+  }
   FQ_SPAN_BEGIN(M::STREAM ? "qual.epilogue" : "seq.epilogue");  dbg_off = (dbg_mask & 128u) != 0;
   if (!dbg_off) hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, final_state, tab.logs,
                      tab.log_prefix, reinterpret_cast<uint32_t *>(out_dev), res);
@@ -307,7 +350,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     }
     FQ_SPAN_BEGIN(M::STREAM ? "qual.index" : "seq.index");
     hipLaunchKernelGGL(k_index_meta<M>, dim3(n_snap / 256 + 1), dim3(256), 0, st, b->raw, b->recs, rec_start, R, n_sym,
-                       stride, sc.tile_bit_base.as<unsigned long long>(), b->index[M::STREAM]);
+                       stride, sc.tile_bit_base.as<unsigned long long>(), tile_path ? TS_TILE : PACK_TILE, b->index[M::STREAM]);
     if (n_snap) {
       const uint32_t *seg_prefix = serial_seq ? sc.seq_plan.as<uint32_t>() + 2 * (B + 1) : arrays + B + (B + 1);
       const uint16_t *entry = serial_seq ? reinterpret_cast<const uint16_t *>(sc.seq_plan.as<uint32_t>() + SEGPLAN_WORDS)

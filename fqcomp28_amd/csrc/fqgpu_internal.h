@@ -112,6 +112,8 @@ struct EncScratch {
   DevBuf tile_bit_base;  // u64 [ptiles+1]
   DevBuf dbg_enc16;   // timing experiments only (FQGPU_DEBUG_NO_ALIAS): enc16 apart from the keys, so that stale keys stay valid
   DevBuf scan_tmp;    // u64 chunk sums for the scans
+  DevBuf tile_runs;   // tile-sorted path: uint2 [tiles][min(B, tile)] run list of every tile (encode.hip: enc_tile_sort.h)
+  DevBuf tile_sync;   // tile-sorted path: u64 status[tiles] | u32 tile counter, pad | u32 run_count[tiles]
 };
 
 // One encode lane: everything a block needs while it is being coded, so that several
@@ -138,6 +140,7 @@ struct fqgpu_ctx {
   unsigned seq_group = 8;        // segments a k_seq_setfunc wave walks in one go, at most (<= SETS_MAX_GROUP)
   unsigned seq_group_min = 16;   // ... as long as a chain keeps this many groups (one per wave of a workgroup)
   bool lds_atomics_ordered = false;  // probed at creation: k_scatter may rank with LDS atomics
+  bool tile_sorted = true;           // tile-sorted partition + fused gather/pack (needs lds_atomics_ordered); false: slot-based path
   unsigned index_stride = 1u << 20;  // symbols between the snapshots of a decode index
   unsigned n_cus = 256;          // compute units of the device (grid of the persistent kernels)
   unsigned n_lanes = 4, next_lane = 0;
