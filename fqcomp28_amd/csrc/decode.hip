@@ -59,31 +59,6 @@ struct TabView {
   const uint32_t *logs, *log_prefix, *dt, *dt_off;
 };
 
-// Backward bit reader (BIT_DStream_t, zstd bitstream.h) in functional form: `pos` = number
-// of unread bits below the end mark; reading nb bits returns bits [pos-nb, pos) of the
-// little-endian bit array, bit pos-1 being the MSB.  A 64-bit register window is refilled
-// from two aligned dwords only when the read position leaves it.
-struct BitReader {
-  g_cu32 *w;           // stream as aligned dwords (buffers are padded)
-  long long pos;
-  long long wbase;     // bit index of window bit 0 (multiple of 32)
-  unsigned long long win;
-  __device__ __forceinline__ void refill() {
-    long long top = (pos + 31) & ~31ll;
-    wbase = top >= 64 ? top - 64 : 0;
-    const unsigned wi = (unsigned)(wbase >> 5);
-    win = (unsigned long long)w[wi] | ((unsigned long long)w[wi + 1] << 32);
-  }
-  __device__ __forceinline__ unsigned read(unsigned nb) {
-    pos -= nb;
-    if (pos < wbase) {
-      if (pos < 0) return 0u;  // corrupt stream: caller checks pos at the end
-      pos += nb; refill(); pos -= nb;
-    }
-    return (unsigned)(win >> (unsigned)(pos - wbase)) & ((1u << nb) - 1u);
-  }
-};
-
 // bits [lo, lo+nb) of the stream, for the data-parallel state load
 __device__ __forceinline__ unsigned peek_bits(g_cu32 *w, long long lo, unsigned nb) {
   const unsigned wi = (unsigned)(lo >> 5);
@@ -91,8 +66,142 @@ __device__ __forceinline__ unsigned peek_bits(g_cu32 *w, long long lo, unsigned 
   return (unsigned)(v >> (unsigned)(lo & 31)) & ((1u << nb) - 1u);
 }
 
+// ---- wave-cooperative walk -------------------------------------------------------------------
+// The chain of one stream is serial: symbol k's DTable entry is dt[context k][state of that context],
+// context k + 1 follows from symbol k.  One lane walking it pays an LDS read plus an L2 (or
+// Infinity Cache) read per symbol, back to back.  The other 63 lanes can shorten that: when
+// symbols .. k - 1 are known, context k + 1 is one of at most 64 (quality: calcContext(s, q[k-1],
+// q[k-2]) for the 64 values s of symbol k; sequence: 4), so lane s fetches the entry that context
+// k + 1 would need IF symbol k is s -- one step before symbol k is known -- and symbol k then only
+// picks a lane (v_readlane).  Two table reads are in flight at any time instead of one: the walk
+// advances two symbols per memory round trip.  A prefetched entry is stale when the context it
+// belongs to was updated after the fetch; that is exactly the case context k + 1 == context k
+// (runs of one quality value, homopolymers): then the entry is read again, behind the update.
+//
+// Backward bit reader (BIT_DStream_t, zstd bitstream.h) in functional form: `pos` = number of unread
+// bits below the end mark; reading nb bits returns bits [pos-nb, pos) of the little-endian bit array,
+// bit pos-1 being the MSB.  The stream travels through a small LDS buffer (all lanes fetch 2 KB at a
+// time, once per ~16 K bits), so the 64-bit register window is refilled from LDS: no bit read of the
+// walking loop ever touches vmcnt, which the two table reads in flight own.
+constexpr unsigned FQ_BITBUF_DW = 512;
+struct LdsBits {
+  g_cu32 *w;
+  uint32_t *buf;        // LDS: stream dwords [buf_lo, buf_lo + FQ_BITBUF_DW)
+  unsigned n_dw;        // dwords of the stream (reads beyond are zeros)
+  unsigned buf_lo;
+  unsigned wdw;         // the window holds stream dwords wdw, wdw + 1
+  unsigned avail;       // unread bits of the window: the read position is bit 32 * wdw + avail of the stream
+  unsigned underflow;   // a read went below bit 0 (corrupt stream)
+  unsigned long long win;
+  __device__ __forceinline__ void fill(unsigned top_dw) {  // all lanes; afterwards the buffer ends with dword top_dw
+    buf_lo = top_dw >= FQ_BITBUF_DW - 1 ? top_dw - (FQ_BITBUF_DW - 1) : 0u;
+    fq_lds_wave_sync();
+    for (unsigned k = threadIdx.x; k < FQ_BITBUF_DW; k += 64) buf[k] = buf_lo + k < n_dw ? w[buf_lo + k] : 0u;
+    fq_lds_wave_sync();
+  }
+  __device__ __forceinline__ void load_window() {
+    if (wdw < buf_lo) fill(wdw + 1);
+    const uint32_t lo = buf[wdw - buf_lo], hi = buf[wdw + 1 - buf_lo];
+    // (kept per lane: with the two words forced into scalar registers by v_readfirstlane the walk
+    // decoded wrong bits on gfx950 / ROCm 7.2 -- measured, cause not found; the window is 2 VGPRs)
+    win = ((unsigned long long)hi << 32) | lo;
+  }
+  __device__ __forceinline__ void init(g_cu32 *words, long long p, uint32_t *lds, unsigned stream_dwords) {
+    w = words; buf = lds; n_dw = stream_dwords; underflow = 0;
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)p), phi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    const long long pu = ((long long)phi << 32) | plo;
+    const long long top = (pu + 31) & ~31ll;
+    wdw = top >= 64 ? (unsigned)(top >> 5) - 2u : 0u;
+    avail = (unsigned)(pu - (long long)wdw * 32);
+    buf_lo = 0;
+    fill(wdw + 1);
+    load_window();
+  }
+  __device__ __forceinline__ long long pos() const { return underflow ? -1ll : (long long)wdw * 32 + avail; }
+  __device__ __forceinline__ unsigned read(unsigned nb) {  // nb <= 12
+    if (avail < nb) {
+      if (wdw == 0) { underflow = 1; avail = 0; return 0u; }  // corrupt stream: the caller checks pos()
+      wdw -= 1; avail += 32;
+      load_window();
+    }
+    avail -= nb;
+    return (unsigned)(win >> avail) & ((1u << nb) - 1u);
+  }
+};
+
+// history of the context model: sequence: the context itself; quality: the last three symbols
+template <class M> struct CtxHist;
+template <> struct CtxHist<SeqModel> {
+  unsigned ctx;
+  __device__ __forceinline__ void start() { ctx = 0xD7u; }  // FSE_Sequence::INITIAL_CONTEXT
+  __device__ __forceinline__ unsigned cur() const { return ctx; }
+  __device__ __forceinline__ unsigned next_if(unsigned s) const { return (ctx >> 2) + ((s & 3u) << 6); }  // addSymUpper
+  __device__ __forceinline__ void push(unsigned s) { ctx = (ctx >> 2) + (s << 6); }
+};
+template <> struct CtxHist<QualModel> {
+  unsigned q, q1, q2;  // symbols k-1, k-2, k-3
+  __device__ __forceinline__ void start() { q = q1 = q2 = 0; }
+  __device__ __forceinline__ unsigned cur() const { return fq_qual_ctx(q, q1, q2); }  // calcContext
+  __device__ __forceinline__ unsigned next_if(unsigned s) const { return fq_qual_ctx(s & 63u, q, q1); }
+  __device__ __forceinline__ void push(unsigned s) { q2 = q1; q1 = q; q = s; }
+};
+
+// entry of context c in its current state, and the context's LDS word it was found through
+__device__ __forceinline__ uint32_t fq_entry_of(const uint32_t *pk, const uint32_t *__restrict__ dt, unsigned c, uint32_t &word) {
+  word = pk[c];
+  return dt[fq_entry_index(word, c)];
+}
+
+// Positions [i0, i1) of one read into out[i0 ..], all 64 lanes of the wave; h = history in front of
+// position i0.  Everything the walk decides on (entry, symbol, context, bit window) is wave-uniform
+// and kept in scalar registers (readfirstlane / readlane), the candidates are per lane.  The loop is
+// unrolled by two with the candidate registers swapped by name: a register copy "cand = next" at the
+// end of an iteration would wait for the load just issued.  Bytes are collected 64 at a time (lane k
+// keeps byte k) and stored as whole lines.
 template <class M>
-__device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *state, uint32_t *dt_off) {
+__device__ __forceinline__ void walk_positions(uint32_t *pk, const uint32_t *__restrict__ dt, LdsBits &br, g_u8 *out,
+                                               unsigned i0, unsigned i1, CtxHist<M> h) {
+  if (i0 >= i1) return;
+  const unsigned lane = threadIdx.x;
+  unsigned ctx = h.cur();
+  uint32_t wv, candw_a, candw_b = 0;
+  uint32_t cur = __builtin_amdgcn_readfirstlane(fq_entry_of(pk, dt, ctx, wv));  // entry of position i0
+  uint32_t curw = __builtin_amdgcn_readfirstlane(wv);
+  uint32_t cand_a = fq_entry_of(pk, dt, h.next_if(lane), candw_a), cand_b = 0;      // position i0 + 1, if symbol i0 is `lane`
+  unsigned keep = 0;
+  // one position: consumes cur, leaves the candidates of position i + 2 in (cout, coutw), picks position i + 1's entry from (cin, cinw)
+  auto step = [&](unsigned i, uint32_t cin, uint32_t cinw, uint32_t &cout, uint32_t &coutw) {
+    const unsigned sym = (cur >> 16) & (unsigned)(M::A - 1);
+    const unsigned ns = (cur & 0xFFFFu) + br.read(cur >> 24);
+    pk[ctx] = (curw & ~0xFFFu) | (ns & 0xFFFu);
+    const unsigned byte = M::STREAM == 0 ? (0x54474341u >> (8u * sym)) & 0xFFu : sym + 33u;  // "ACGT"[sym] / Phred + 33
+    keep = lane == ((i - i0) & 63u) ? byte : keep;
+    if (((i - i0) & 63u) == 63u) out[i - 63u + lane] = (uint8_t)keep;
+    const unsigned prev_ctx = ctx;
+    h.push(sym);
+    ctx = h.cur();
+    cout = fq_entry_of(pk, dt, h.next_if(lane), coutw);  // behind the update above, in front of the one of position i + 1
+    if (ctx == prev_ctx) {  // (uniform) the prefetched entry is older than the update: read again
+      uint32_t w2;
+      cur = __builtin_amdgcn_readfirstlane(fq_entry_of(pk, dt, ctx, w2));
+      curw = __builtin_amdgcn_readfirstlane(w2);
+    } else {
+      cur = (uint32_t)__builtin_amdgcn_readlane((int)cin, (int)sym);
+      curw = (uint32_t)__builtin_amdgcn_readlane((int)cinw, (int)sym);
+    }
+  };
+  unsigned i = i0;
+  for (; i + 2 <= i1; i += 2) {
+    step(i, cand_a, candw_a, cand_b, candw_b);
+    step(i + 1, cand_b, candw_b, cand_a, candw_a);
+  }
+  if (i < i1) step(i, cand_a, candw_a, cand_b, candw_b);
+  const unsigned n = i1 - i0, tail = n & 63u;
+  if (lane < tail) out[i1 - tail + lane] = (uint8_t)keep;
+}
+
+template <class M>
+__device__ void decode_stream(const DecJob &j, const TabView &tab, uint32_t *pk, uint32_t *bitbuf) {
   constexpr unsigned B = M::B;
   const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
@@ -113,55 +222,35 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint16_t *sta
   for (unsigned c = lane; c < B; c += 64) {
     const unsigned lg = tab.logs[c];
     const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
-    state[c] = (uint16_t)peek_bits(w, lo, lg);
-    dt_off[c] = tab.dt_off[c] + 1u;  // skip the DTable header word
+    pk[c] = fq_pack_state(tab.dt_off[c], c, peek_bits(w, lo, lg));
   }
   __syncthreads();
-  if (lane != 0) return;
 
-  BitReader br;
-  br.w = w;
-  br.pos = p0 - (long long)sum_logs;
-  br.refill();
+  LdsBits br;
+  br.init(w, p0 - (long long)sum_logs, bitbuf, (len + 3) / 4);
   const uint32_t *__restrict__ dt = tab.dt;
-  for (unsigned r = j.n_recs; r > 0; r--) {  // records last -> first
-    fqgpu_rec rec;
-    rec.seq_off = recs[r - 1].seq_off; rec.qual_off = recs[r - 1].qual_off; rec.len = recs[r - 1].len;
-    if (M::STREAM == 0) {
-      g_u8 *out = raw + rec.seq_off;
-      unsigned ctx = 0xD7u;  // FSE_Sequence::INITIAL_CONTEXT
-      for (unsigned i = 0; i < rec.len; i++) {
-        const uint32_t e = dt[dt_off[ctx] + state[ctx]];
-        const unsigned sym = (e >> 16) & 3u;
-        state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
-        out[i] = (uint8_t)(0x54474341u >> (8u * sym));  // "ACGT"[sym]
-        ctx = (ctx >> 2) + (sym << 6);                   // addSymUpper
-      }
-    } else {
-      g_u8 *out = raw + rec.qual_off;
-      unsigned ctx = 1u << 12, q1 = 0, q2 = 0;  // calcContext(0,0,0)
-      for (unsigned i = 0; i < rec.len; i++) {
-        const uint32_t e = dt[dt_off[ctx] + state[ctx]];
-        const unsigned q = (e >> 16) & 63u;
-        state[ctx] = (uint16_t)((e & 0xFFFFu) + br.read(e >> 24));
-        out[i] = (uint8_t)(q + 33u);
-        ctx = fq_qual_ctx(q, q1, q2);
-        q2 = q1;
-        q1 = q;
-      }
-    }
-    if (br.pos < 0) break;
+  fqgpu_rec nxt;
+  nxt.seq_off = recs[j.n_recs - 1].seq_off; nxt.qual_off = recs[j.n_recs - 1].qual_off; nxt.len = recs[j.n_recs - 1].len;
+  for (unsigned r = j.n_recs; r > 0; r--) {  // records last -> first (src/workspace.cpp:84-87)
+    const fqgpu_rec rec = nxt;
+    if (r > 1) { nxt.seq_off = recs[r - 2].seq_off; nxt.qual_off = recs[r - 2].qual_off; nxt.len = recs[r - 2].len; }  // lands while this record is walked
+    CtxHist<M> h;
+    h.start();
+    walk_positions<M>(pk, dt, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), 0u, rec.len, h);
+    if (br.underflow) break;
   }
   // BIT_endOfDStream (src/fse_common.hpp:141): every bit consumed, none invented
-  if (br.pos != 0) res->corrupt = 1;
-  res->total_bits = (unsigned long long)(p0 - (long long)sum_logs);
+  if (lane == 0) {
+    if (br.pos() != 0) res->corrupt = 1;
+    res->total_bits = (unsigned long long)(p0 - (long long)sum_logs);
+  }
 }
 
 // One stride of one stream, started from a snapshot of the decode index (or from the end of the
 // stream for the last stride): encode indices [e_lo, e_hi) in decoder order, i.e. from the record
 // and position of symbol e_hi - 1 towards the front of the block.
 template <class M>
-__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, uint32_t *pk) {
+__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, uint32_t *pk, uint32_t *bitbuf) {
   constexpr unsigned B = M::B;
   const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
@@ -203,15 +292,12 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     if (pos > (long long)len * 8) { if (lane == 0) res->corrupt = 1; return; }
   }
   __syncthreads();
-  if (lane != 0) return;
   // every bit of this stride consumed, none invented: the walk must end where the previous
   // snapshot (or the start of the stream) says
   const long long pos_end = chunk == 0 ? 0ll : (long long)*reinterpret_cast<const unsigned long long *>(snaps + (size_t)(chunk - 1) * snap_bytes);
 
-  BitReader br;
-  br.w = w;
-  br.pos = pos;
-  br.refill();
+  LdsBits br;
+  br.init(w, pos, bitbuf, (len + 3) / 4);
   const uint32_t *__restrict__ dt = tab.dt;
   unsigned r = fq_locate((const uint32_t *)j.rec_start, 0, j.n_recs - 1, e_hi - 1);  // record of symbol e_hi - 1
   bool first = true;
@@ -222,56 +308,36 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     // positions of this record inside [e_lo, e_hi): encode index of position i is rs + len - 1 - i
     const unsigned i0 = first ? rec.len - 1u - (e_hi - 1u - rs) : 0u;
     const unsigned i1 = rs >= e_lo ? rec.len : rec.len - (e_lo - rs);  // one past the last position
-    if (M::STREAM == 0) {
-      g_u8 *out = raw + rec.seq_off;
-      unsigned ctx = 0xD7u;  // FSE_Sequence::INITIAL_CONTEXT
-      if (first && !from_end)
+    CtxHist<M> h;
+    h.start();
+    if (first && !from_end) {  // the stride starts inside a read: the model has seen the bytes in front
+      if constexpr (M::STREAM == 0) {
         for (int b = 3; b >= 0; b--) {
           const unsigned ch = (prev >> (8 * b)) & 0xFFu;
-          if (ch != 0xFFu) ctx = (ctx >> 2) + (fq_base_code(ch) << 6);
+          if (ch != 0xFFu) h.push(fq_base_code(ch));
         }
-      for (unsigned i = i0; i < i1; i++) {
-        const uint32_t v = pk[ctx];
-        const uint32_t e = dt[fq_entry_index(v, ctx)];
-        const unsigned sym = (e >> 16) & 3u;
-        pk[ctx] = (v & ~0xFFFu) | ((e & 0xFFFFu) + br.read(e >> 24));
-        out[i] = (uint8_t)(0x54474341u >> (8u * sym));
-        ctx = (ctx >> 2) + (sym << 6);
-      }
-    } else {
-      g_u8 *out = raw + rec.qual_off;
-      unsigned ctx = 1u << 12, q1 = 0, q2 = 0;  // calcContext(0,0,0)
-      if (first && !from_end) {
+      } else {
         const unsigned a = prev & 0xFFu, b = (prev >> 8) & 0xFFu, c = (prev >> 16) & 0xFFu;
-        const unsigned qa = a != 0xFFu ? (a - 33u) & 63u : 0u, qb = b != 0xFFu ? (b - 33u) & 63u : 0u,
-                       qc = c != 0xFFu ? (c - 33u) & 63u : 0u;
-        ctx = fq_qual_ctx(qa, qb, qc);
-        q1 = qa; q2 = qb;
-      }
-      for (unsigned i = i0; i < i1; i++) {
-        const uint32_t v = pk[ctx];
-        const uint32_t e = dt[fq_entry_index(v, ctx)];
-        const unsigned q = (e >> 16) & 63u;
-        pk[ctx] = (v & ~0xFFFu) | ((e & 0xFFFFu) + br.read(e >> 24));
-        out[i] = (uint8_t)(q + 33u);
-        ctx = fq_qual_ctx(q, q1, q2);
-        q2 = q1;
-        q1 = q;
+        h.q = a != 0xFFu ? (a - 33u) & 63u : 0u;
+        h.q1 = b != 0xFFu ? (b - 33u) & 63u : 0u;
+        h.q2 = c != 0xFFu ? (c - 33u) & 63u : 0u;
       }
     }
+    walk_positions<M>(pk, dt, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), i0, i1, h);
     first = false;
-    if (br.pos < 0 || rs <= e_lo || r == 0) break;
+    if (br.underflow || rs <= e_lo || r == 0) break;
     r--;
   }
-  if (br.pos != pos_end) res->corrupt = 1;
+  if (lane == 0 && br.pos() != pos_end) res->corrupt = 1;
 }
 
 __global__ void __launch_bounds__(64)
 k_decode_chunks(const DecJob *__restrict__ jobs, const DecChunk *__restrict__ chunks, TabView seq_tab, TabView qual_tab) {
   __shared__ uint32_t pk[QualModel::B];
+  __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
   const DecChunk ch = chunks[blockIdx.x];
-  if (ch.stream) decode_chunk<QualModel>(jobs[ch.job], ch.chunk, qual_tab, pk);
-  else decode_chunk<SeqModel>(jobs[ch.job], ch.chunk, seq_tab, pk);
+  if (ch.stream) decode_chunk<QualModel>(jobs[ch.job], ch.chunk, qual_tab, pk, bitbuf);
+  else decode_chunk<SeqModel>(jobs[ch.job], ch.chunk, seq_tab, pk, bitbuf);
 }
 
 // record lengths of one block, for the encode index of the first symbol of every record
@@ -285,10 +351,10 @@ k_lens_of(const fqgpu_rec *__restrict__ recs, unsigned n, uint32_t *__restrict__
 // dispatched first, the sequence streams behind them
 __global__ void __launch_bounds__(64)
 k_decode(const DecJob *__restrict__ jobs, unsigned n_blocks, TabView seq_tab, TabView qual_tab) {
-  __shared__ uint16_t state[QualModel::B];
-  __shared__ uint32_t dt_off[QualModel::B];
-  if (blockIdx.x < n_blocks) decode_stream<QualModel>(jobs[blockIdx.x], qual_tab, state, dt_off);
-  else decode_stream<SeqModel>(jobs[blockIdx.x - n_blocks], seq_tab, state, dt_off);
+  __shared__ uint32_t pk[QualModel::B];
+  __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
+  if (blockIdx.x < n_blocks) decode_stream<QualModel>(jobs[blockIdx.x], qual_tab, pk, bitbuf);
+  else decode_stream<SeqModel>(jobs[blockIdx.x - n_blocks], seq_tab, pk, bitbuf);
 }
 
 // batch-wide record arrays: N counts widened for the scan
