@@ -18,7 +18,7 @@
 // bit-identical to the slot-based path (kept as the fallback when the probe of
 // fq_probe_lds_atomic_order fails).
 constexpr unsigned TS_TILE = 32768;    // symbols per tile (lpos16 and the 16-bit cursors hold 0 .. 32768)
-constexpr unsigned TS_BATCH = 2048;    // symbols ranked between two workgroup barriers (K3: 74 KB of LDS, two workgroups per CU)
+constexpr unsigned TS_BATCH = 4096;    // symbols ranked between two workgroup barriers (K3: 72 KB of LDS, two workgroups per CU)
 constexpr unsigned TS_THREADS = 512;   // K3
 constexpr unsigned TS_WAVES = TS_THREADS / 64;
 constexpr unsigned TS_GP_THREADS = 256;  // K6: 76 KB of LDS, two workgroups per CU
@@ -107,8 +107,18 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   constexpr unsigned NCHUNK = B / 64;  // 64 contexts per chunk: 128 (quality) / 4 (sequence)
   __shared__ uint32_t cursor32[B / 2];  // 16-bit cursors (local positions), two per word
   __shared__ __attribute__((aligned(16))) uint8_t lsym[TS_TILE + 64];  // the tile's symbols in sorted order (+ a dump for idle lanes)
-  __shared__ uint4 kb4[2][TS_BATCH / 8], sb4[2][QUAL ? TS_BATCH / 16 : 1];
-  __shared__ TsRunMap rm;
+  // two batch buffers: batch j is ranked while the loading waves write batch j + 1 into the other one --
+  // from REGISTERS they filled one batch earlier -- and request batch j + 2 into those registers: the
+  // loads stay in flight across the barrier (it waits for LDS only), so nobody ever sits at a barrier
+  // waiting for global memory (with loads that went straight to LDS the ranking wave waited out a
+  // memory round trip per batch: half of this kernel).  The run map lives in the same bytes: it is
+  // built when the last batch has been ranked.
+  constexpr unsigned NBUF = 2;
+  constexpr unsigned KB_BYTES = NBUF * (TS_BATCH / 8) * 16, SB_BYTES = QUAL ? NBUF * (TS_BATCH / 16) * 16 : 16;
+  __shared__ __attribute__((aligned(16))) uint8_t stage_raw[(KB_BYTES + SB_BYTES) > sizeof(TsRunMap) ? (KB_BYTES + SB_BYTES) : sizeof(TsRunMap)];
+  uint4 (*kb4)[TS_BATCH / 8] = reinterpret_cast<uint4 (*)[TS_BATCH / 8]>(stage_raw);
+  uint4 (*sb4)[QUAL ? TS_BATCH / 16 : 1] = reinterpret_cast<uint4 (*)[QUAL ? TS_BATCH / 16 : 1]>(stage_raw + KB_BYTES);
+  TsRunMap &rm = *reinterpret_cast<TsRunMap *>(stage_raw);
   __shared__ unsigned wsum[TS_WAVES], s_cnt[NCHUNK < 2 ? 2 : NCHUNK], s_nruns;
   uint16_t *cur16 = reinterpret_cast<uint16_t *>(cursor32);
   const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), tid = threadIdx.x, wave = tid >> 6, lane = fq_lane();
@@ -145,30 +155,46 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   TS_PROF(PS + 0);
   // ---- ranking, batch by batch
   const unsigned nbatch = (nt + TS_BATCH - 1) / TS_BATCH;
-  auto load_batch = [&](unsigned j, unsigned t, unsigned nthreads) {  // keys (and symbols) of batch j -> LDS
+  // the loading waves (448 threads): thread t < 512 owns one 16-byte piece of a batch's keys, thread
+  // 512 <= t' < 768 (quality) one piece of its symbols -- at most two pieces per thread
+  static_assert(TS_BATCH / 8 == 512 && TS_BATCH / 16 == 256, "piece ownership below assumes a 4096-symbol batch");
+  const unsigned mt = tid - 64;  // loader thread number (valid for tid >= 64)
+  uint4 rk0 = make_uint4(0, 0, 0, 0), rk1 = rk0, rs0 = rk0;
+  auto request = [&](unsigned j) {  // batch j -> registers (loaders)
     const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + e0 + j * TS_BATCH);  // 16-byte aligned; arrays are padded by a batch
-    for (unsigned i = t; i < TS_BATCH / 8; i += nthreads) kb4[j & 1][i] = gk[i];
-    if (QUAL) {
-      const uint4 *gs = reinterpret_cast<const uint4 *>(csym + e0 + j * TS_BATCH);
-      for (unsigned i = t; i < TS_BATCH / 16; i += nthreads) sb4[j & 1][i] = gs[i];
-    }
+    rk0 = gk[mt];
+    if (mt + 448 < 512) rk1 = gk[mt + 448];
+    if (QUAL && mt < 256) rs0 = reinterpret_cast<const uint4 *>(csym + e0 + j * TS_BATCH)[mt];
+  };
+  auto deposit = [&](unsigned j) {  // registers -> LDS buffer of batch j (loaders)
+    kb4[j % NBUF][mt] = rk0;
+    if (mt + 448 < 512) kb4[j % NBUF][mt + 448] = rk1;
+    if (QUAL && mt < 256) sb4[j % NBUF][mt] = rs0;
   };
   // Barrier of the batch loop: LDS traffic only.  __syncthreads() also drains vmcnt, i.e. the ranking
-  // wave would wait at every barrier for its position stores (fire and forget) to reach memory; the
-  // loading waves' data dependences (global load -> LDS store) already cover their loads.
+  // wave would wait at every barrier for its position stores (fire and forget) to reach memory and the
+  // loaders for the batch they have just requested.
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  load_batch(0, tid, TS_THREADS);
+  {  // batch 0 by everybody, straight to LDS
+    const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + e0);
+    for (unsigned i = tid; i < TS_BATCH / 8; i += TS_THREADS) kb4[0][i] = gk[i];
+    if (QUAL) {
+      const uint4 *gs = reinterpret_cast<const uint4 *>(csym + e0);
+      for (unsigned i = tid; i < TS_BATCH / 16; i += TS_THREADS) sb4[0][i] = gs[i];
+    }
+  }
+  if (wave != 0 && nbatch > 1) request(1);
   __syncthreads();
   for (unsigned j = 0; j < nbatch; j++) {
     if (wave == 0) {
-      const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j & 1]);
-      const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j & 1]);
+      const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j % NBUF]);
+      const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j % NBUF]);
       uint16_t *gpos = lpos16 + e0 + j * TS_BATCH;  // the ranking wave stores the positions itself: 128 contiguous bytes per instruction
       const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
       // Wave-uniform trip count with the bound checked inside: with a per-lane trip count the
       // compiler's unrolling lets low lanes run ahead of high lanes by a whole group of iterations,
       // and the rank is only right if iteration k of every lane precedes iteration k + 1 of any lane.
-      // Software-pipelined by hand, TS_GROUP iterations at a time: all key reads, then all atomics
+      // Software-pipelined by hand, G iterations at a time: all key reads, then all atomics
       // (the LDS executes them in program order), then all stores -- three LDS round trips per group
       // instead of three per iteration: the loop is a pure latency chain and ONE wave ranks a tile.
       // Branch-free: a lane beyond the batch adds 0 to cursor word 0 and stores into the spare bytes
@@ -178,7 +204,7 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
 #ifdef FQGPU_EXPERIMENTS
       const unsigned long long tr0 = wall_clock64();
 #endif
-      for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // no global memory operation in here
+      for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // nothing in here waits for global memory
         unsigned key[G], pos[G], sy[G];
 #pragma unroll
         for (unsigned g = 0; g < G; g++) {
@@ -203,14 +229,15 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
       if (lane == 0) atomicAdd(&g_ts_prof[PS + 4], wall_clock64() - tr0);
 #endif
     } else {
-      if (j + 1 < nbatch) load_batch(j + 1, tid - 64, TS_THREADS - 64);
+      if (j + 1 < nbatch) deposit(j + 1);  // requested one batch ago
+      if (j + 2 < nbatch) request(j + 2);
     }
     lds_barrier();
   }
   TS_PROF(PS + 1);
 
   // ---- the tile's runs, in context order: cur16[c] is now the END of context c's run
-  uint16_t *run_unused = nullptr; (void)run_unused;
+  __syncthreads();  // (also drains the ranking wave's position stores) the batch buffers are dead: the run map takes their place
   ts_clear_bitmap<TS_THREADS>(rm);
   unsigned long long my_mask[(NCHUNK + TS_WAVES - 1) / TS_WAVES];
   unsigned my_beg[(NCHUNK + TS_WAVES - 1) / TS_WAVES], my_len[(NCHUNK + TS_WAVES - 1) / TS_WAVES];

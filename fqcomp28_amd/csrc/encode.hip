@@ -141,7 +141,10 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if ((rc = sc.ctx_arrays.reserve((size_t)(4 * B + 3) * 4))) return rc;
   if ((rc = sc.seg_state.reserve((size_t)B * 2 + (size_t)B * 8))) return rc;
   // sequence chains: segment length of the candidate-set kernels
-  unsigned seq_S = ctx->seq_segment ? ctx->seq_segment : auto_S;
+  // (sequence chains: a lane of k_seq_emit walks one segment, a pure latency chain -- blocks of 64 MiB
+  // and less gain 4 % from 2048-symbol segments, 256 MiB blocks nothing)
+  const unsigned auto_seq_S = n_sym >= (48u << 20) ? 4096u : n_sym >= (4u << 20) ? 2048u : 1024u;
+  unsigned seq_S = ctx->seq_segment ? ctx->seq_segment : auto_seq_S;
   seq_S = (unsigned)min(((size_t)seq_S + SETS_BLOCK - 1) / SETS_BLOCK * SETS_BLOCK, (size_t)1 << 30);
   const unsigned seq_max_segs = n_sym / seq_S + B + 1;
   const unsigned seq_fstride = 1u << tab.max_log;
