@@ -475,7 +475,7 @@ def main():
                            "ratio_vs_reference": (round(check["gpu_bytes"] / check["oracle_bytes"], 6) if check else None),
                            "ratio_vs_reference_from": "seq+qual bytes of one whole timed block / the CPU oracle's bytes for the same block and tables",
                            "longest_serial_chain": [list(r) for r in longest]},
-            "oracle_check": check,
+            "oracle_check": check, "kernel_sources_sha": kernel_sources_sha(),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_decode": cpu_dec, "setup_s": round(setup_s, 1),
         }
         line.update(extra)

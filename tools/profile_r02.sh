@@ -1,0 +1,21 @@
+#!/bin/bash
+# The profile passes of one round, to be run on the GPU box in ONE gpurun call from the repo root:
+#   gpurun --timeout 1100 -- 'bash tools/profile_r02.sh'
+# Every pass is its own rocprofv3 run (counters never share a run with another trace domain); the
+# summaries land under gpurun_out/r02_*/ and tools/refresh_profiles.py copies them into profiles/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --skip-cpu --skip-decode --skip-host"
+rm -rf $O/r02_prof4 $O/r02_prof1 $O/r02_pmc_f $O/r02_pmc_w $O/r02_pmc_sq
+# 1. per-kernel time of the timed encode region, default lanes (4 blocks in flight)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_prof4 -o p4 -- $B > $O/r02_prof4.log 2>&1 && echo "prof4 ok" &&
+# 2. the same with one block in flight
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_prof1 -o p1 -- $B --lanes 1 --steps 2 > $O/r02_prof1.log 2>&1 && echo "prof1 ok" &&
+# 3./4. HBM bytes per launch: FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/r02_pmc_f -o f -- $B --steps 1 --warmup 1 > $O/r02_pmc_f.log 2>&1 && echo "pmc_f ok" &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/r02_pmc_w -o w -- $B --steps 1 --warmup 1 > $O/r02_pmc_w.log 2>&1 && echo "pmc_w ok" &&
+# 5. wave-cycle breakdown, one block in flight
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/r02_pmc_sq -o sq -- $B --steps 1 --warmup 1 --lanes 1 > $O/r02_pmc_sq.log 2>&1 && echo "pmc_sq ok"
+ls $O/r02_prof4 $O/r02_pmc_f | head -20
