@@ -485,6 +485,7 @@ def main():
         print(json.dumps(line))
     ctx.close()
     if dist is not None:
+        farm.barrier(dist)  # rank 0 runs the checks and baselines alone: the others wait for it here
         dist.destroy_process_group()
 
 

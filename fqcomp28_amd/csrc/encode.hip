@@ -131,7 +131,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   // keys: ckey u16 | csym u8 (quality), later enc16 u16 over both;  slot_of: u32 -- padded by one batch
   const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15;  // keeps every sub-array 16-byte aligned
   static_assert(TILE_SEQ % SEQ_BATCH == 0 && SEQ_BATCH % PACK_TILE == 0 && TILE_QUAL % PACK_TILE == 0, "a packing tile lies inside one partition tile");
-  if ((rc = sc.slot_of.reserve(n_pad * 4))) return rc;
+  if ((rc = sc.slot_of.reserve(n_pad * (tile_path ? 2 : 4)))) return rc;  // tile path: lpos16 (u16) lives here; slot path: slot_of (u32)
   if ((rc = sc.keys.reserve(n_pad * 3))) return rc;
   if ((rc = sc.sorted_sym.reserve(padded))) return rc;
   if ((rc = sc.out16.reserve(padded * 2))) return rc;
