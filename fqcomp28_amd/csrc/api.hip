@@ -395,6 +395,7 @@ extern "C" int fqgpu_ctx_create(int device, const void *seq_ft, const void *qual
   rc = fq_probe_lds_atomic_order(ctx->stream, &ctx->lds_atomics_ordered);
   if (getenv("FQGPU_NO_LDS_ATOMIC_RANK")) ctx->lds_atomics_ordered = false;  // force the ballot kernel
   if (getenv("FQGPU_SLOT_PARTITION")) ctx->tile_sorted = false;  // the slot-based partition/gather (same bits, for comparisons)
+  if (const char *e = getenv("FQGPU_SETFUNC_WGS")) ctx->setfunc_wgs = (unsigned)atoi(e);  // experiments: same bits
   if (const char *e = getenv("FQGPU_SEQ_GROUP")) ctx->seq_group = (unsigned)atoi(e);  // experiments
   if (const char *e = getenv("FQGPU_SEQ_GROUP_MIN")) ctx->seq_group_min = (unsigned)atoi(e);
   if (!rc) rc = upload_tables(ctx, 0, seq_ft);

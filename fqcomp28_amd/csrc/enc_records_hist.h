@@ -243,6 +243,99 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   }
 }
 
+// K1 for BOTH streams in one pass (tile-sorted path: the two streams share the tile geometry).  The
+// encoder as a whole is bound by instruction issue, and the two K1 launches each
+// walked the records, located every symbol and ran the same software pipeline: here that part is done
+// once per symbol and only the window load, the context arithmetic, the key store and the histogram
+// atomic are per stream.
+__global__ void __launch_bounds__(256)
+k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
+             const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
+             uint32_t *__restrict__ tile_hist_seq, uint16_t *__restrict__ ckey_seq,
+             uint32_t *__restrict__ tile_hist_qual, uint16_t *__restrict__ ckey_qual, uint8_t *__restrict__ csym_qual,
+             BlockResult *res) {
+  constexpr unsigned BS = SeqModel::B, BQ = QualModel::B;
+  __shared__ uint32_t hist_s[BS];
+  __shared__ uint32_t hist_q[BQ / 2];  // 16-bit counters, two per word (T <= 32768: they cannot wrap)
+  __shared__ RecCache rcache[4];  // one per wave
+  __shared__ uint8_t code_lut[256], sym_lut[256];
+  code_lut[threadIdx.x & 255u] = (uint8_t)fq_base_code(threadIdx.x & 255u);
+  sym_lut[threadIdx.x & 255u] = (uint8_t)fq_base_sym(threadIdx.x & 255u);
+  const unsigned tile = blockIdx.x;
+  const unsigned e0 = tile * T;
+  const unsigned e1 = min(e0 + T, n_sym);
+  for (unsigned c = threadIdx.x; c < BS; c += blockDim.x) hist_s[c] = 0;
+  for (unsigned c = threadIdx.x; c < BQ / 2; c += blockDim.x) hist_q[c] = 0;
+  __syncthreads();
+  const unsigned wave = threadIdx.x >> 6, lane = fq_lane();
+  const unsigned per = (((e1 - e0) + blockDim.x - 1u) / blockDim.x) * 64u;
+  const unsigned wb = min(e0 + wave * per, e1), we = min(wb + per, e1);
+  bool bad_s = false, bad_q = false;
+  if (wb < we) {
+    SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb), R, &rcache[wave], 0};
+    SymBytes bs[K1_DEPTH], bq[K1_DEPTH];
+    unsigned bp[K1_DEPTH];
+    unsigned lim = 0;
+    auto fetch = [&](int slot, unsigned eb2) {
+      const unsigned e2 = eb2 + lane;
+      const bool v2 = e2 < lim;
+      fqgpu_rec rec;
+      unsigned p;
+      w.locate(eb2, lim, e2, v2, rec, p);
+      bs[slot] = fq_load_sym_bytes<SeqModel>(raw, rec, p, v2);
+      bq[slot] = fq_load_sym_bytes<QualModel>(raw, rec, p, v2);
+      bp[slot] = p;
+    };
+    auto consume = [&](int slot, unsigned eb2) {
+      const unsigned e = eb2 + lane;
+      if (e < lim) {
+        unsigned ctx, sym;
+        fq_ctx_from_bytes<SeqModel>(bs[slot], bp[slot], ctx, sym, code_lut, sym_lut);
+        bad_s |= sym >= (unsigned)SeqModel::A;
+        ckey_seq[e] = (uint16_t)(ctx | ((sym & 3u) << 8));
+        atomicAdd(&hist_s[ctx], 1u);
+        fq_ctx_from_bytes<QualModel>(bq[slot], bp[slot], ctx, sym, code_lut, sym_lut);
+        bad_q |= sym >= (unsigned)QualModel::A;
+        ckey_qual[e] = (uint16_t)ctx;
+        csym_qual[e] = (uint8_t)(sym & 63u);
+        atomicAdd(&hist_q[ctx >> 1], 1u << (16u * (ctx & 1u)));
+      }
+    };
+    for (unsigned eb = wb; eb < we;) {
+      const unsigned covered = w.refill(w.r);
+      lim = covered >= we ? we : wb + ((covered - wb) & ~63u);
+#pragma unroll
+      for (int d = 0; d < K1_DEPTH - 1; d++)
+        if (eb + 64u * d < lim) fetch(d, eb + 64u * d);
+      for (; eb + 64u * (2 * K1_DEPTH - 2) < lim; eb += 64u * K1_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < K1_DEPTH; d++) {
+          fetch((d + K1_DEPTH - 1) % K1_DEPTH, eb + 64u * (d + K1_DEPTH - 1));
+          consume(d, eb + 64u * d);
+        }
+      }
+      for (; eb < lim; eb += 64u * K1_DEPTH) {  // drain
+#pragma unroll
+        for (int d = 0; d < K1_DEPTH; d++) {
+          const unsigned cur = eb + 64u * d;
+          if (cur < lim) {
+            const unsigned nxt = cur + 64u * (K1_DEPTH - 1);
+            if (nxt < lim) fetch((d + K1_DEPTH - 1) % K1_DEPTH, nxt);
+            consume(d, cur);
+          }
+        }
+      }
+      eb = lim;
+    }
+  }
+  if (bad_s) atomicOr(&res->s[0].bad_symbol, 1u);
+  if (bad_q) atomicOr(&res->s[1].bad_symbol, 1u);
+  __syncthreads();
+  for (unsigned c = threadIdx.x; c < BS; c += blockDim.x) tile_hist_seq[(size_t)tile * BS + c] = hist_s[c];
+  for (unsigned c = threadIdx.x; c < BQ; c += blockDim.x)
+    tile_hist_qual[(size_t)tile * BQ + c] = (hist_q[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu;
+}
+
 // ------------------------------------------------------------------ K2: layout of the sorted arrays
 // group_sum[g][c] = sum of tile_hist over the tiles of group g
 __global__ void __launch_bounds__(256)

@@ -97,6 +97,22 @@ static constexpr int fq_debug_k1() { return 0; }
 static constexpr bool fq_debug_flag(const char *) { return false; }
 #endif
 
+// true: both streams take the tile-sorted path, so K1 can run once for both (k_tile_hist2)
+static bool fused_k1(const fqgpu_ctx *ctx) {
+  return ctx->lds_atomics_ordered && ctx->tile_sorted && !ctx->seq_generic && !fq_debug_skip() && !fq_debug_k1();
+}
+
+// keys and tile histograms of one stream exist before its pipeline starts (fused K1)
+template <class M>
+int reserve_k1(EncScratch &sc, unsigned n_sym) {
+  const unsigned n_tiles = (n_sym + TS_TILE - 1) / TS_TILE;
+  const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15;
+  int rc;
+  if ((rc = sc.keys.reserve(n_pad * 3))) return rc;
+  if ((rc = sc.tile_hist.reserve((size_t)n_tiles * M::B * 4))) return rc;
+  return FQGPU_OK;
+}
+
 template <class M>
 int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b,
                   const uint32_t *rec_start, uint8_t *out_dev, size_t cap, unsigned flags) {
@@ -182,7 +198,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   const char *pfx = M::STREAM ? "qual." : "seq.";
   (void)pfx;
 
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");  dbg_off = (dbg_mask & 1u) != 0;
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");  dbg_off = (dbg_mask & 1u) != 0 || fused_k1(ctx);
   if (!dbg_off) hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs,
                      rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), ckey, csym, res,
                      fq_debug_k1());
@@ -245,7 +261,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     if (!dbg_skip) {
       if (dbg_off) {
       } else if (two)
-        hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(min(max_fitems, ctx->n_cus)), dim3(SETS_WAVES2 * 64),
+        hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(min(max_fitems, ctx->setfunc_wgs ? ctx->setfunc_wgs : ctx->n_cus)), dim3(SETS_WAVES2 * 64),
                            32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2,
                            4 * next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 4 * (B + 1));
       else
@@ -455,6 +471,17 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
   hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
   FQ_SPAN_END();
 
+  if (fused_k1(ctx)) {  // K1 of both streams in one pass, in front of the fork
+    const unsigned n_sym = (unsigned)b->n_bases, n_tiles = (n_sym + TS_TILE - 1) / TS_TILE;
+    if ((rc = reserve_k1<SeqModel>(lane.enc[0], n_sym)) || (rc = reserve_k1<QualModel>(lane.enc[1], n_sym))) return rc;
+    const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15;
+    uint16_t *kq = lane.enc[1].keys.as<uint16_t>();
+    FQ_SPAN_BEGIN("tile_hist2");
+    hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R, n_sym, TS_TILE,
+                       lane.enc[0].tile_hist.as<uint32_t>(), lane.enc[0].keys.as<uint16_t>(), lane.enc[1].tile_hist.as<uint32_t>(), kq,
+                       reinterpret_cast<uint8_t *>(kq + n_pad), b->result);
+    FQ_SPAN_END();
+  }
   FQ_HIP(hipEventRecord(lane.ev_fork, lane.st_seq));
   FQ_HIP(hipStreamWaitEvent(lane.st_qual, lane.ev_fork, 0));
   // timing experiments only (wrong output): one stream at a time

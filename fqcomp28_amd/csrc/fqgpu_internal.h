@@ -142,7 +142,8 @@ struct fqgpu_ctx {
   bool lds_atomics_ordered = false;  // probed at creation: k_scatter may rank with LDS atomics
   bool tile_sorted = true;           // tile-sorted partition + fused gather/pack (needs lds_atomics_ordered); false: slot-based path
   unsigned index_stride = 1u << 20;  // symbols between the snapshots of a decode index
-  unsigned n_cus = 256;          // compute units of the device (grid of the persistent kernels)
+  unsigned n_cus = 256;          // compute units of the device
+  unsigned setfunc_wgs = 0;      // persistent workgroups of k_seq_setfunc (0 = default, see fqgpu_ctx_create)
   unsigned n_lanes = 4, next_lane = 0;
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch
