@@ -37,6 +37,23 @@ k_readlens_ncount(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__
   }
 }
 
+// Tile-sorted path: the read lengths alone (record table only: the raw block is not touched); the N's are
+// counted by K1 (k_tile_hist2), which sees every base anyway, into n_cnt32 -- zeroed here.
+__global__ void __launch_bounds__(256)
+k_readlens(const fqgpu_rec *__restrict__ recs, unsigned R, uint16_t *__restrict__ readlens,
+           uint32_t *__restrict__ n_cnt32, uint32_t *__restrict__ lens32) {
+  for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+    const unsigned len = recs[r].len;
+    readlens[r] = (uint16_t)len;
+    lens32[r] = len;
+    n_cnt32[r] = 0;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_ncount16(const uint32_t *__restrict__ n_cnt32, unsigned R, uint16_t *__restrict__ n_count) {
+  for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) n_count[r] = (uint16_t)n_cnt32[r];
+}
+
 // N position deltas (second half of replaceAndEncodeNs) + optional N -> A write-back
 __global__ void __launch_bounds__(256)
 k_npos(uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R,
@@ -107,15 +124,22 @@ struct SymbolWalker {
   // inside the cached window (no global memory operation in here).
   __device__ __forceinline__ void locate(unsigned eb, unsigned e_end, unsigned e, bool valid,
                                          fqgpu_rec &rec, unsigned &p) {
+    unsigned ridx;
+    locate(eb, e_end, e, valid, rec, p, ridx);
+  }
+  // ... and the record's number
+  __device__ __forceinline__ void locate(unsigned eb, unsigned e_end, unsigned e, bool valid,
+                                         fqgpu_rec &rec, unsigned &p, unsigned &ridx) {
     const unsigned chunk_end = min(eb + 64u, e_end);
     unsigned rr = r;
     rec.seq_off = rec.qual_off = rec.len = 0;
     p = 0;
+    ridx = 0;
     for (;;) {
       const unsigned k = rr - r0;
       const unsigned rs = __builtin_amdgcn_readfirstlane(cache->start[k]),
                      rn = __builtin_amdgcn_readfirstlane(cache->start[k + 1]);
-      if (valid && e >= rs && e < rn) { rec = cache->rec[k]; p = rec.len - 1u - (e - rs); }
+      if (valid && e >= rs && e < rn) { rec = cache->rec[k]; p = rec.len - 1u - (e - rs); ridx = rr; }
       if (rn > chunk_end) break;            // record rr continues into the next chunk
       rr++;
       if (rn == chunk_end) break;           // next chunk starts exactly at record rr
@@ -253,14 +277,14 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
              const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
              uint32_t *__restrict__ tile_hist_seq, uint16_t *__restrict__ ckey_seq,
              uint32_t *__restrict__ tile_hist_qual, uint16_t *__restrict__ ckey_qual, uint8_t *__restrict__ csym_qual,
-             BlockResult *res) {
+             uint32_t *__restrict__ n_cnt32, BlockResult *res) {
   constexpr unsigned BS = SeqModel::B, BQ = QualModel::B;
   __shared__ uint32_t hist_s[BS];
   __shared__ uint32_t hist_q[BQ / 2];  // 16-bit counters, two per word (T <= 32768: they cannot wrap)
   __shared__ RecCache rcache[4];  // one per wave
   __shared__ uint8_t code_lut[256], sym_lut[256];
   code_lut[threadIdx.x & 255u] = (uint8_t)fq_base_code(threadIdx.x & 255u);
-  sym_lut[threadIdx.x & 255u] = (uint8_t)fq_base_sym(threadIdx.x & 255u);
+  sym_lut[threadIdx.x & 255u] = (uint8_t)fq_base_sym_n(threadIdx.x & 255u);  // bit 6: the byte is an N
   const unsigned tile = blockIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
@@ -274,14 +298,14 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
   if (wb < we) {
     SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb), R, &rcache[wave], 0};
     SymBytes bs[K1_DEPTH], bq[K1_DEPTH];
-    unsigned bp[K1_DEPTH];
+    unsigned bp[K1_DEPTH], br[K1_DEPTH];
     unsigned lim = 0;
     auto fetch = [&](int slot, unsigned eb2) {
       const unsigned e2 = eb2 + lane;
       const bool v2 = e2 < lim;
       fqgpu_rec rec;
       unsigned p;
-      w.locate(eb2, lim, e2, v2, rec, p);
+      w.locate(eb2, lim, e2, v2, rec, p, br[slot]);
       bs[slot] = fq_load_sym_bytes<SeqModel>(raw, rec, p, v2);
       bq[slot] = fq_load_sym_bytes<QualModel>(raw, rec, p, v2);
       bp[slot] = p;
@@ -291,7 +315,8 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
       if (e < lim) {
         unsigned ctx, sym;
         fq_ctx_from_bytes<SeqModel>(bs[slot], bp[slot], ctx, sym, code_lut, sym_lut);
-        bad_s |= sym >= (unsigned)SeqModel::A;
+        bad_s |= (sym & FQ_SYM_BAD_MASK) != 0;
+        if (sym & FQ_SYM_IS_N) atomicAdd(&n_cnt32[br[slot]], 1u);  // (rare) replaceAndEncodeNs's n_count, src/fse_sequence.cpp:35-51
         ckey_seq[e] = (uint16_t)(ctx | ((sym & 3u) << 8));
         atomicAdd(&hist_s[ctx], 1u);
         fq_ctx_from_bytes<QualModel>(bq[slot], bp[slot], ctx, sym, code_lut, sym_lut);

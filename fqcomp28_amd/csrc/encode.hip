@@ -464,14 +464,21 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
   FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), st));
   const unsigned rec_blocks = (unsigned)min((size_t)(R + 3) / 4, (size_t)8192);  // k_npos: a wave per record
   const unsigned len_blocks = (unsigned)min((size_t)(R + 15) / 16, (size_t)4096);  // four records per wave
+  const bool fused = fused_k1(ctx);
   FQ_SPAN_BEGIN("records");
-  hipLaunchKernelGGL(k_readlens_ncount, dim3(len_blocks), dim3(256), 0, st, b->raw, b->recs, R,
-                     b->readlens, b->n_count, n_cnt32, lens32);
-  if ((rc = fq_scan2_u32_to_u32(st, lens32, n_cnt32, R, rec_start, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
-  hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
+  if (fused) {  // lengths from the record table alone; K1 counts the N's (the raw block is read once less)
+    hipLaunchKernelGGL(k_readlens, dim3((unsigned)min((size_t)(R + 255) / 256, (size_t)2048)), dim3(256), 0, st, b->recs, R, b->readlens,
+                       n_cnt32, lens32);
+    if ((rc = fq_scan_u32_to_u32(st, lens32, R, rec_start, lane.scan_tmp))) return rc;
+  } else {
+    hipLaunchKernelGGL(k_readlens_ncount, dim3(len_blocks), dim3(256), 0, st, b->raw, b->recs, R,
+                       b->readlens, b->n_count, n_cnt32, lens32);
+    if ((rc = fq_scan2_u32_to_u32(st, lens32, n_cnt32, R, rec_start, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
+    hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
+  }
   FQ_SPAN_END();
 
-  if (fused_k1(ctx)) {  // K1 of both streams in one pass, in front of the fork
+  if (fused) {  // K1 of both streams in one pass, in front of the fork
     const unsigned n_sym = (unsigned)b->n_bases, n_tiles = (n_sym + TS_TILE - 1) / TS_TILE;
     if ((rc = reserve_k1<SeqModel>(lane.enc[0], n_sym)) || (rc = reserve_k1<QualModel>(lane.enc[1], n_sym))) return rc;
     const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15;
@@ -479,7 +486,7 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
     FQ_SPAN_BEGIN("tile_hist2");
     hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R, n_sym, TS_TILE,
                        lane.enc[0].tile_hist.as<uint32_t>(), lane.enc[0].keys.as<uint16_t>(), lane.enc[1].tile_hist.as<uint32_t>(), kq,
-                       reinterpret_cast<uint8_t *>(kq + n_pad), b->result);
+                       reinterpret_cast<uint8_t *>(kq + n_pad), n_cnt32, b->result);
     FQ_SPAN_END();
   }
   FQ_HIP(hipEventRecord(lane.ev_fork, lane.st_seq));
@@ -493,6 +500,11 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
 
   // after both streams: the optional in-place N -> A must not race with their reads of raw
   FQ_SPAN_BEGIN("npos");
+  if (fused) {  // K1 left the N counts: 16-bit copy for the caller, offsets of the position deltas
+    hipLaunchKernelGGL(k_ncount16, dim3((unsigned)min((size_t)(R + 255) / 256, (size_t)2048)), dim3(256), 0, st, n_cnt32, R, b->n_count);
+    if ((rc = fq_scan_u32_to_u32(st, n_cnt32, R, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
+    hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
+  }
   hipLaunchKernelGGL(k_npos, dim3(rec_blocks), dim3(256), 0, st, b->raw, b->recs, R,
                      lane.n_off.as<uint32_t>(), b->n_pos, (flags & FQGPU_F_WRITE_BACK_N) ? 1 : 0);
   FQ_SPAN_END();

@@ -291,6 +291,9 @@ __device__ __forceinline__ unsigned fq_base_code(unsigned c) {
 __device__ __forceinline__ unsigned fq_base_sym(unsigned c) {
   return (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') ? fq_base_code(c) : 4u;
 }
+// the same with bit 6 set for 'N' (K1 of the tile-sorted path counts the N's of every read on the way)
+constexpr unsigned FQ_SYM_IS_N = 0x40u, FQ_SYM_BAD_MASK = 0x3Cu;
+__device__ __forceinline__ unsigned fq_base_sym_n(unsigned c) { return fq_base_sym(c) | (c == 'N' ? FQ_SYM_IS_N : 0u); }
 
 // FSE_Quality::calcContext (src/fse_quality.h:40-44)
 __device__ __forceinline__ unsigned fq_qual_ctx(unsigned q, unsigned q1, unsigned q2) {
