@@ -42,19 +42,14 @@ typedef FQ_GLOBAL uint8_t g_u8;
 typedef const FQ_GLOBAL uint32_t g_cu32;
 typedef const FQ_GLOBAL fqgpu_rec g_crec;
 
-// Per context ONE LDS word: decoder state (12 bits, log <= 12) | the context's DTable position.
-// DTables lie back to back, 1 + 2^log words each (log >= 5), so dt_off[c] - c is a multiple of 32
-// and (dt_off[c] - c) / 32 < 2^20: word = that << 12 | state; entry = dt[(word >> 12) * 32 + c + 1 + state].
-// 32 KB of LDS per quality lane instead of 48 KB (16-bit states + 32-bit offsets): five lanes per CU
-// for the strides of the indexed decode, where the number of resident lanes is what counts (the
-// one-lane-per-stream kernel keeps the two arrays: one ALU op less on its dependent chain).
-__device__ __forceinline__ uint32_t fq_pack_state(uint32_t dt_off_c, unsigned c, unsigned state) {
-  return (((dt_off_c - c) >> 5) << 12) | (state & 0xFFFu);
-}
-__device__ __forceinline__ uint32_t fq_entry_index(uint32_t word, unsigned c) {
-  return ((word >> 12) << 5) + c + 1u + (word & 0xFFFu);
-}
-
+// Per context TWO LDS words: the DTable entry of the context's CURRENT state and the position of the
+// context's table (index of its state-0 entry in dt).  The decoder never needs the state itself
+// again once the entry is there: the next state is entry.newState + bits, i.e. the next entry is
+// dt[table + that].  DTables lie back to back, 1 + 2^log words each.
+struct CtxEntry {
+  uint32_t entry, table;
+};
+typedef __attribute__((address_space(3))) CtxEntry lds_CtxEntry;  // the compiler must see LDS, not a generic pointer (flat_load)
 struct TabView {
   const uint32_t *logs, *log_prefix, *dt, *dt_off;
 };
@@ -66,66 +61,82 @@ __device__ __forceinline__ unsigned peek_bits(g_cu32 *w, long long lo, unsigned 
   return (unsigned)(v >> (unsigned)(lo & 31)) & ((1u << nb) - 1u);
 }
 
-// ---- wave-cooperative walk -------------------------------------------------------------------
-// The chain of one stream is serial: symbol k's DTable entry is dt[context k][state of that context],
-// context k + 1 follows from symbol k.  One lane walking it pays an LDS read plus an L2 (or
-// Infinity Cache) read per symbol, back to back.  The other 63 lanes can shorten that: when
-// symbols .. k - 1 are known, context k + 1 is one of at most 64 (quality: calcContext(s, q[k-1],
-// q[k-2]) for the 64 values s of symbol k; sequence: 4), so lane s fetches the entry that context
-// k + 1 would need IF symbol k is s -- one step before symbol k is known -- and symbol k then only
-// picks a lane (v_readlane).  Two table reads are in flight at any time instead of one: the walk
-// advances two symbols per memory round trip.  A prefetched entry is stale when the context it
-// belongs to was updated after the fetch; that is exactly the case context k + 1 == context k
-// (runs of one quality value, homopolymers): then the entry is read again, behind the update.
+// ---- the walk -------------------------------------------------------------------------------
+// The chain of one stream is serial: symbol k's DTable entry is dt[table of context k + state of
+// that context], context k + 1 follows from symbol k.  Looked up when it is needed, that is an L2
+// (or Infinity Cache) read per symbol on the dependent chain.  But the entry a context will need
+// NEXT is known the moment the context is left: its new state is entry.newState + bits.  So the
+// walk keeps, per context, the entry of the current state in LDS (CtxEntry) and refills it when the
+// context is used: an LDS-DMA load (global_load_lds_dword, lane 0) of dt[table + new state]
+// straight into the context's LDS slot -- no register, nothing waits for it.  The dependent chain
+// of a symbol is: entry (scalar) -> symbol -> next context -> ONE LDS read.
+//
+// A context that comes back before its refill has landed (runs of one quality value,
+// homopolymers) must wait for it.  The slot itself says so: before the refill is issued the slot's
+// entry is overwritten with FQ_ENTRY_PENDING (no real entry: nbBits <= 12), the DMA replaces it
+// with the new entry, and a reader that finds the mark drains the vector-memory counter and reads
+// again.  Order: LDS operations of a wave complete in issue order and the mark is waited for
+// (lgkmcnt) before the DMA is issued, so the mark can never overwrite the refill; a second refill
+// of a context cannot be issued before the first one has been read, i.e. has landed.
+//
+// One wave per stream, and that wave is bound by the number of instructions it issues per symbol
+// (about one per 4-5 cycles, more for a taken branch), not by memory: the loop is written to be
+// straight-line -- the bit reader reads its two stream words from the LDS buffer every symbol
+// instead of branching on a register window, the DMA is issued under an EXEC mask set in the
+// assembly, bytes are collected four per register and sixty-four registers per store.
+//
+// The refill is issued from inline assembly: the compiler then does not know of an LDS-DMA in
+// flight, and does not put a vmcnt(0) in front of every later LDS read.  Its own counted waits
+// stay correct (operations it does not know of only make them wait for more).
 //
 // Backward bit reader (BIT_DStream_t, zstd bitstream.h) in functional form: `pos` = number of unread
 // bits below the end mark; reading nb bits returns bits [pos-nb, pos) of the little-endian bit array,
 // bit pos-1 being the MSB.  The stream travels through a small LDS buffer (all lanes fetch 2 KB at a
-// time, once per ~16 K bits), so the 64-bit register window is refilled from LDS: no bit read of the
-// walking loop ever touches vmcnt, which the two table reads in flight own.
+// time, once per ~16 K bits); position = 32 * wdw + avail, 0 <= avail < 32.
 constexpr unsigned FQ_BITBUF_DW = 512;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct LdsBits {
   g_cu32 *w;
-  uint32_t *buf;        // LDS: stream dwords [buf_lo, buf_lo + FQ_BITBUF_DW)
+  lds_u32 *buf;         // LDS: stream dwords [buf_lo, buf_lo + FQ_BITBUF_DW)
   unsigned n_dw;        // dwords of the stream (reads beyond are zeros)
-  unsigned buf_lo;
-  unsigned wdw;         // the window holds stream dwords wdw, wdw + 1
-  unsigned avail;       // unread bits of the window: the read position is bit 32 * wdw + avail of the stream
+  int buf_lo;
+  int wdw;              // the next bits are read from stream dwords wdw, wdw + 1
+  int avail;
   unsigned underflow;   // a read went below bit 0 (corrupt stream)
-  unsigned long long win;
-  __device__ __forceinline__ void fill(unsigned top_dw) {  // all lanes; afterwards the buffer ends with dword top_dw
-    buf_lo = top_dw >= FQ_BITBUF_DW - 1 ? top_dw - (FQ_BITBUF_DW - 1) : 0u;
+  __device__ __forceinline__ void fill(int top_dw) {  // all lanes; afterwards the buffer ends with dword top_dw
+    buf_lo = top_dw >= (int)FQ_BITBUF_DW - 1 ? top_dw - ((int)FQ_BITBUF_DW - 1) : 0;
     fq_lds_wave_sync();
-    for (unsigned k = threadIdx.x; k < FQ_BITBUF_DW; k += 64) buf[k] = buf_lo + k < n_dw ? w[buf_lo + k] : 0u;
+    for (unsigned k = threadIdx.x; k < FQ_BITBUF_DW; k += 64) buf[k] = (unsigned)buf_lo + k < n_dw ? w[(unsigned)buf_lo + k] : 0u;
     fq_lds_wave_sync();
-  }
-  __device__ __forceinline__ void load_window() {
-    if (wdw < buf_lo) fill(wdw + 1);
-    const uint32_t lo = buf[wdw - buf_lo], hi = buf[wdw + 1 - buf_lo];
-    // (kept per lane: with the two words forced into scalar registers by v_readfirstlane the walk
-    // decoded wrong bits on gfx950 / ROCm 7.2 -- measured, cause not found; the window is 2 VGPRs)
-    win = ((unsigned long long)hi << 32) | lo;
   }
   __device__ __forceinline__ void init(g_cu32 *words, long long p, uint32_t *lds, unsigned stream_dwords) {
-    w = words; buf = lds; n_dw = stream_dwords; underflow = 0;
+    w = words; buf = (lds_u32 *)lds; n_dw = stream_dwords; underflow = 0;
     const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)p), phi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
     const long long pu = ((long long)phi << 32) | plo;
-    const long long top = (pu + 31) & ~31ll;
-    wdw = top >= 64 ? (unsigned)(top >> 5) - 2u : 0u;
-    avail = (unsigned)(pu - (long long)wdw * 32);
-    buf_lo = 0;
+    wdw = (int)(pu >> 5);
+    avail = (int)(pu & 31);
     fill(wdw + 1);
-    load_window();
   }
   __device__ __forceinline__ long long pos() const { return underflow ? -1ll : (long long)wdw * 32 + avail; }
-  __device__ __forceinline__ unsigned read(unsigned nb) {  // nb <= 12
-    if (avail < nb) {
-      if (wdw == 0) { underflow = 1; avail = 0; return 0u; }  // corrupt stream: the caller checks pos()
-      wdw -= 1; avail += 32;
-      load_window();
-    }
-    avail -= nb;
-    return (unsigned)(win >> avail) & ((1u << nb) - 1u);
+  // the rare part of advance(): the buffer has run out, or the stream has (corrupt: the caller checks
+  // pos(); what is read from then on is arbitrary but stays inside the tables)
+  __device__ __forceinline__ void turn() {
+    if (wdw < 0) { underflow = 1; wdw = 0; avail = 0; }
+    if (wdw < buf_lo) fill(wdw + 1);
+  }
+  // A read in two parts, so that the walk can put the LDS access where it wants it: advance(nb) moves
+  // the position below the nb bits and returns the two stream dwords they lie in, bits() cuts them out.
+  __device__ __forceinline__ uint2 advance(unsigned nb) {  // nb <= 12; uniform
+    avail -= (int)nb;
+    const int borrow = avail >> 31;
+    wdw += borrow;
+    avail += borrow & 32;
+    if (__builtin_expect(wdw < buf_lo, 0)) turn();
+    const lds_u32 *q = buf + (wdw - buf_lo);
+    return make_uint2(q[0], q[1]);
+  }
+  __device__ __forceinline__ unsigned bits(uint2 win, unsigned nb) const {
+    return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(win.y, win.x, (unsigned)avail), 0u, nb);
   }
 };
 
@@ -146,62 +157,100 @@ template <> struct CtxHist<QualModel> {
   __device__ __forceinline__ void push(unsigned s) { q2 = q1; q1 = q; q = s; }
 };
 
-// entry of context c in its current state, and the context's LDS word it was found through
-__device__ __forceinline__ uint32_t fq_entry_of(const uint32_t *pk, const uint32_t *__restrict__ dt, unsigned c, uint32_t &word) {
-  word = pk[c];
-  return dt[fq_entry_index(word, c)];
+// What a stream's walk carries from read to read: the per-context entries (LDS) and the table.
+constexpr uint32_t FQ_ENTRY_PENDING = 0xFFFFFFFFu;
+struct Walk {
+  lds_CtxEntry *ce;        // at LDS byte address ce_lds (< 64 KB: the DMA's M0 offset)
+  unsigned ce_lds;
+  const uint32_t *dt;
+  __device__ __forceinline__ void init(CtxEntry *lds, const uint32_t *tables) {
+    ce = (lds_CtxEntry *)lds;
+    ce_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ce);
+    dt = tables;
+  }
+  __device__ __forceinline__ void mark(unsigned c) const { ce[c].entry = FQ_ENTRY_PENDING; }
+  __device__ __forceinline__ uint2 load(unsigned c) const { return make_uint2(ce[c].entry, ce[c].table); }  // (one ds_read_b64)
+  // ce[c].entry <- dt[idx], asynchronously, behind mark(c): lane 0 alone issues (EXEC = 1; the walk
+  // runs with all 64 lanes); the LDS destination of an LDS-DMA load is M0 + 4 * lane id.
+  // lgkmcnt(1): LDS operations complete in issue order and the load() of the next entry was issued
+  // behind the mark (the compiler cannot swap the two: they may alias), so at most that load, or
+  // one behind it, is still on its way -- the mark has landed.
+  // M0 is not restored: nothing else in these kernels uses it (no other LDS-DMA, no movrel).
+  __device__ __forceinline__ void refill(unsigned c, unsigned idx) const {
+    const unsigned off = idx * 4u;  // < 2^27 entries
+    const unsigned dst = __builtin_amdgcn_readfirstlane(ce_lds + c * (unsigned)sizeof(CtxEntry));
+    asm volatile("s_waitcnt lgkmcnt(1)\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 1\n\t"
+                 "global_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
+                 : : "v"(off), "s"(dt), "s"(dst) : "memory");
+  }
+  // entry of context c from what load(c) returned; a pending entry is waited for
+  __device__ __forceinline__ uint32_t take(unsigned c, uint2 e) const {
+    uint32_t entry = __builtin_amdgcn_readfirstlane(e.x);
+    if (__builtin_expect(entry == FQ_ENTRY_PENDING, 0)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      entry = __builtin_amdgcn_readfirstlane(ce[c].entry);
+    }
+    return entry;
+  }
+};
+
+// four symbols, one per byte -> their four output bytes
+template <class M>
+__device__ __forceinline__ unsigned fq_sym_bytes(unsigned acc) {
+  return M::STREAM == 0 ? __builtin_amdgcn_perm(0u, 0x54474341u, acc)  // "ACGT"[sym] per byte
+                        : acc + 0x21212121u;                             // Phred + 33
 }
 
 // Positions [i0, i1) of one read into out[i0 ..], all 64 lanes of the wave; h = history in front of
-// position i0.  Everything the walk decides on (entry, symbol, context, bit window) is wave-uniform
-// and kept in scalar registers (readfirstlane / readlane), the candidates are per lane.  The loop is
-// unrolled by two with the candidate registers swapped by name: a register copy "cand = next" at the
-// end of an iteration would wait for the load just issued.  Bytes are collected 64 at a time (lane k
-// keeps byte k) and stored as whole lines.
+// position i0.  Everything the walk decides on (entry, symbol, context, bit position) is wave-uniform
+// and kept in scalar registers.  Lane k keeps output bytes 4k .. 4k + 3 of the current 256.
 template <class M>
-__device__ __forceinline__ void walk_positions(uint32_t *pk, const uint32_t *__restrict__ dt, LdsBits &br, g_u8 *out,
-                                               unsigned i0, unsigned i1, CtxHist<M> h) {
+__device__ __forceinline__ void walk_positions(Walk &wk, LdsBits &br, g_u8 *out, unsigned i0, unsigned i1, CtxHist<M> h) {
   if (i0 >= i1) return;
   const unsigned lane = threadIdx.x;
   unsigned ctx = h.cur();
-  uint32_t wv, candw_a, candw_b = 0;
-  uint32_t cur = __builtin_amdgcn_readfirstlane(fq_entry_of(pk, dt, ctx, wv));  // entry of position i0
-  uint32_t curw = __builtin_amdgcn_readfirstlane(wv);
-  uint32_t cand_a = fq_entry_of(pk, dt, h.next_if(lane), candw_a), cand_b = 0;      // position i0 + 1, if symbol i0 is `lane`
-  unsigned keep = 0;
-  // one position: consumes cur, leaves the candidates of position i + 2 in (cout, coutw), picks position i + 1's entry from (cin, cinw)
-  auto step = [&](unsigned i, uint32_t cin, uint32_t cinw, uint32_t &cout, uint32_t &coutw) {
+  uint2 e = wk.load(ctx);
+  uint32_t cur = wk.take(ctx, e);
+  unsigned keep = 0, acc = 0;
+  // one symbol; j = its byte in acc.  Order: the stream dwords of this symbol's bits are asked for
+  // first (their address needs nbBits only), then the next context's entry (the chain); the refill's
+  // arithmetic runs while that entry is on its way.
+  auto step = [&](unsigned j) {
+    const unsigned nb = cur >> 24;
+    const uint2 win = br.advance(nb);
     const unsigned sym = (cur >> 16) & (unsigned)(M::A - 1);
-    const unsigned ns = (cur & 0xFFFFu) + br.read(cur >> 24);
-    pk[ctx] = (curw & ~0xFFFu) | (ns & 0xFFFu);
-    const unsigned byte = M::STREAM == 0 ? (0x54474341u >> (8u * sym)) & 0xFFu : sym + 33u;  // "ACGT"[sym] / Phred + 33
-    keep = lane == ((i - i0) & 63u) ? byte : keep;
-    if (((i - i0) & 63u) == 63u) out[i - 63u + lane] = (uint8_t)keep;
-    const unsigned prev_ctx = ctx;
     h.push(sym);
-    ctx = h.cur();
-    cout = fq_entry_of(pk, dt, h.next_if(lane), coutw);  // behind the update above, in front of the one of position i + 1
-    if (ctx == prev_ctx) {  // (uniform) the prefetched entry is older than the update: read again
-      uint32_t w2;
-      cur = __builtin_amdgcn_readfirstlane(fq_entry_of(pk, dt, ctx, w2));
-      curw = __builtin_amdgcn_readfirstlane(w2);
-    } else {
-      cur = (uint32_t)__builtin_amdgcn_readlane((int)cin, (int)sym);
-      curw = (uint32_t)__builtin_amdgcn_readlane((int)cinw, (int)sym);
-    }
+    const unsigned nctx = h.cur();
+    wk.mark(ctx);
+    const uint2 ne = wk.load(nctx);
+    const unsigned idx = (cur & 0xFFFFu) + e.y + br.bits(win, nb);  // (e.y, the table, stays in its vector register)
+    acc |= sym << (8u * j);
+    wk.refill(ctx, idx);
+    ctx = nctx;
+    e = ne;
+    cur = wk.take(ctx, e);  // (one too many at the end of a read: the next read starts from another context)
   };
-  unsigned i = i0;
-  for (; i + 2 <= i1; i += 2) {
-    step(i, cand_a, candw_a, cand_b, candw_b);
-    step(i + 1, cand_b, candw_b, cand_a, candw_a);
+  g_u8 *o = out + i0;
+  const unsigned n = i1 - i0;
+  unsigned g = 0;  // symbols done
+  for (; g + 4 <= n; g += 4) {
+    acc = 0;
+    step(0); step(1); step(2); step(3);
+    const unsigned slot = (g >> 2) & 63u;
+    keep = lane == slot ? fq_sym_bytes<M>(acc) : keep;
+    if (slot == 63u) *reinterpret_cast<FQ_GLOBAL uint32_t *>(o + (g - 252u) + 4u * lane) = keep;  // (reads start anywhere: unaligned dwords)
   }
-  if (i < i1) step(i, cand_a, candw_a, cand_b, candw_b);
-  const unsigned n = i1 - i0, tail = n & 63u;
-  if (lane < tail) out[i1 - tail + lane] = (uint8_t)keep;
+  const unsigned r = n - g;  // < 4 symbols left
+  acc = 0;
+  for (unsigned j = 0; j < r; j++) step(j);
+  const unsigned full = (g >> 2) & 63u;  // whole dwords not stored yet
+  const unsigned base = g - 4u * full;
+  if (lane < full) *reinterpret_cast<FQ_GLOBAL uint32_t *>(o + base + 4u * lane) = keep;
+  if (lane < r) o[g + lane] = (uint8_t)(fq_sym_bytes<M>(acc) >> (8u * lane));
 }
 
 template <class M>
-__device__ void decode_stream(const DecJob &j, const TabView &tab, uint32_t *pk, uint32_t *bitbuf) {
+__device__ void decode_stream(const DecJob &j, const TabView &tab, CtxEntry *ce, uint32_t *bitbuf) {
   constexpr unsigned B = M::B;
   const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
@@ -222,13 +271,16 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint32_t *pk,
   for (unsigned c = lane; c < B; c += 64) {
     const unsigned lg = tab.logs[c];
     const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
-    pk[c] = fq_pack_state(tab.dt_off[c], c, peek_bits(w, lo, lg));
+    const uint32_t table = tab.dt_off[c] + 1u;  // behind the table's header word
+    ce[c].table = table;
+    ce[c].entry = tab.dt[table + peek_bits(w, lo, lg)];
   }
   __syncthreads();
+  Walk wk;
+  wk.init(ce, tab.dt);
 
   LdsBits br;
   br.init(w, p0 - (long long)sum_logs, bitbuf, (len + 3) / 4);
-  const uint32_t *__restrict__ dt = tab.dt;
   fqgpu_rec nxt;
   nxt.seq_off = recs[j.n_recs - 1].seq_off; nxt.qual_off = recs[j.n_recs - 1].qual_off; nxt.len = recs[j.n_recs - 1].len;
   for (unsigned r = j.n_recs; r > 0; r--) {  // records last -> first (src/workspace.cpp:84-87)
@@ -236,7 +288,7 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint32_t *pk,
     if (r > 1) { nxt.seq_off = recs[r - 2].seq_off; nxt.qual_off = recs[r - 2].qual_off; nxt.len = recs[r - 2].len; }  // lands while this record is walked
     CtxHist<M> h;
     h.start();
-    walk_positions<M>(pk, dt, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), 0u, rec.len, h);
+    walk_positions<M>(wk, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), 0u, rec.len, h);
     if (br.underflow) break;
   }
   // BIT_endOfDStream (src/fse_common.hpp:141): every bit consumed, none invented
@@ -250,7 +302,7 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, uint32_t *pk,
 // stream for the last stride): encode indices [e_lo, e_hi) in decoder order, i.e. from the record
 // and position of symbol e_hi - 1 towards the front of the block.
 template <class M>
-__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, uint32_t *pk, uint32_t *bitbuf) {
+__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, CtxEntry *ce, uint32_t *bitbuf) {
   constexpr unsigned B = M::B;
   const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
@@ -277,7 +329,9 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     if (p0 < (long long)sum_logs) { if (lane == 0) res->corrupt = 1; return; }
     for (unsigned c = lane; c < B; c += 64) {
       const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
-      pk[c] = fq_pack_state(tab.dt_off[c], c, peek_bits(w, lo, tab.logs[c]));
+      const uint32_t table = tab.dt_off[c] + 1u;
+      ce[c].table = table;
+      ce[c].entry = tab.dt[table + peek_bits(w, lo, tab.logs[c])];
     }
     pos = p0 - (long long)sum_logs;
     if (lane == 0) res->total_bits = (unsigned long long)pos;
@@ -285,7 +339,9 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     const uint8_t *snap = snaps + (size_t)chunk * snap_bytes;  // snapshot chunk + 1 sits at e_hi
     const uint16_t *st = reinterpret_cast<const uint16_t *>(snap + FQ_INDEX_SNAP_HEAD);
     for (unsigned c = lane; c < B; c += 64) {
-      pk[c] = fq_pack_state(tab.dt_off[c], c, (unsigned)st[c] & ((1u << tab.logs[c]) - 1u));  // a damaged index must not leave the table
+      const uint32_t table = tab.dt_off[c] + 1u;
+      ce[c].table = table;
+      ce[c].entry = tab.dt[table + ((unsigned)st[c] & ((1u << tab.logs[c]) - 1u))];  // a damaged index must not leave the table
     }
     pos = (long long)*reinterpret_cast<const unsigned long long *>(snap);
     prev = reinterpret_cast<const uint32_t *>(snap)[2];
@@ -298,7 +354,8 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
 
   LdsBits br;
   br.init(w, pos, bitbuf, (len + 3) / 4);
-  const uint32_t *__restrict__ dt = tab.dt;
+  Walk wk;
+  wk.init(ce, tab.dt);
   unsigned r = fq_locate((const uint32_t *)j.rec_start, 0, j.n_recs - 1, e_hi - 1);  // record of symbol e_hi - 1
   bool first = true;
   for (;;) {
@@ -323,7 +380,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
         h.q2 = c != 0xFFu ? (c - 33u) & 63u : 0u;
       }
     }
-    walk_positions<M>(pk, dt, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), i0, i1, h);
+    walk_positions<M>(wk, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), i0, i1, h);
     first = false;
     if (br.underflow || rs <= e_lo || r == 0) break;
     r--;
@@ -333,11 +390,11 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
 
 __global__ void __launch_bounds__(64)
 k_decode_chunks(const DecJob *__restrict__ jobs, const DecChunk *__restrict__ chunks, TabView seq_tab, TabView qual_tab) {
-  __shared__ uint32_t pk[QualModel::B];
+  __shared__ CtxEntry ce[QualModel::B];
   __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
   const DecChunk ch = chunks[blockIdx.x];
-  if (ch.stream) decode_chunk<QualModel>(jobs[ch.job], ch.chunk, qual_tab, pk, bitbuf);
-  else decode_chunk<SeqModel>(jobs[ch.job], ch.chunk, seq_tab, pk, bitbuf);
+  if (ch.stream) decode_chunk<QualModel>(jobs[ch.job], ch.chunk, qual_tab, ce, bitbuf);
+  else decode_chunk<SeqModel>(jobs[ch.job], ch.chunk, seq_tab, ce, bitbuf);
 }
 
 // record lengths of one block, for the encode index of the first symbol of every record
@@ -351,10 +408,10 @@ k_lens_of(const fqgpu_rec *__restrict__ recs, unsigned n, uint32_t *__restrict__
 // dispatched first, the sequence streams behind them
 __global__ void __launch_bounds__(64)
 k_decode(const DecJob *__restrict__ jobs, unsigned n_blocks, TabView seq_tab, TabView qual_tab) {
-  __shared__ uint32_t pk[QualModel::B];
+  __shared__ CtxEntry ce[QualModel::B];
   __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
-  if (blockIdx.x < n_blocks) decode_stream<QualModel>(jobs[blockIdx.x], qual_tab, pk, bitbuf);
-  else decode_stream<SeqModel>(jobs[blockIdx.x - n_blocks], seq_tab, pk, bitbuf);
+  if (blockIdx.x < n_blocks) decode_stream<QualModel>(jobs[blockIdx.x], qual_tab, ce, bitbuf);
+  else decode_stream<SeqModel>(jobs[blockIdx.x - n_blocks], seq_tab, ce, bitbuf);
 }
 
 // batch-wide record arrays: N counts widened for the scan
