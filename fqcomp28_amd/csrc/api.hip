@@ -528,6 +528,7 @@ extern "C" int fqgpu_ctx_dump_tables(fqgpu_ctx *ctx, int stream, unsigned model,
   if (dtable_out) {
     if (dtable_cap_words < dw) return FQGPU_E_ARG;
     FQ_HIP(hipMemcpy(dtable_out, t.dt + dof, dw * 4, hipMemcpyDeviceToHost));
+    for (size_t k = 1; k < dw; k++) dtable_out[k] = FQ_DENTRY_TO_ZSTD(dtable_out[k]);  // the device keeps the walk's arrangement
   }
   return FQGPU_OK;
 }

@@ -98,10 +98,12 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct LdsBits {
   g_cu32 *w;
   lds_u32 *buf;         // LDS: stream dwords [buf_lo, buf_lo + FQ_BITBUF_DW)
+  unsigned buf_bits;    // 8 * LDS byte address of buf (a multiple of 32)
   unsigned n_dw;        // dwords of the stream (reads beyond are zeros)
   int buf_lo;
-  int wdw;              // the next bits are read from stream dwords wdw, wdw + 1
-  int avail;
+  // the read position as a BIT address in LDS: buf_bits + 32 * (stream dword - buf_lo) + bit; one
+  // subtraction per read, the dword's LDS address and the shift count are both cut out of it
+  unsigned p;
   unsigned underflow;   // a read went below bit 0 (corrupt stream)
   __device__ __forceinline__ void fill(int top_dw) {  // all lanes; afterwards the buffer ends with dword top_dw
     buf_lo = top_dw >= (int)FQ_BITBUF_DW - 1 ? top_dw - ((int)FQ_BITBUF_DW - 1) : 0;
@@ -109,86 +111,93 @@ struct LdsBits {
     for (unsigned k = threadIdx.x; k < FQ_BITBUF_DW; k += 64) buf[k] = (unsigned)buf_lo + k < n_dw ? w[(unsigned)buf_lo + k] : 0u;
     fq_lds_wave_sync();
   }
-  __device__ __forceinline__ void init(g_cu32 *words, long long p, uint32_t *lds, unsigned stream_dwords) {
-    w = words; buf = (lds_u32 *)lds; n_dw = stream_dwords; underflow = 0;
-    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)p), phi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
-    const long long pu = ((long long)phi << 32) | plo;
-    wdw = (int)(pu >> 5);
-    avail = (int)(pu & 31);
+  __device__ __forceinline__ void place(int wdw, int avail) {  // position = bit `avail` of stream dword wdw
     fill(wdw + 1);
+    p = buf_bits + 32u * (unsigned)(wdw - buf_lo) + (unsigned)avail;
   }
-  __device__ __forceinline__ long long pos() const { return underflow ? -1ll : (long long)wdw * 32 + avail; }
+  __device__ __forceinline__ void init(g_cu32 *words, long long pos0, uint32_t *lds, unsigned stream_dwords) {
+    w = words; buf = (lds_u32 *)lds; n_dw = stream_dwords; underflow = 0;
+    buf_bits = __builtin_amdgcn_readfirstlane((unsigned)(size_t)buf) * 8u;
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pos0), phi = __builtin_amdgcn_readfirstlane((unsigned)(pos0 >> 32));
+    const long long pu = ((long long)phi << 32) | plo;
+    place((int)(pu >> 5), (int)(pu & 31));
+  }
+  __device__ __forceinline__ long long pos() const { return underflow ? -1ll : (long long)buf_lo * 32 + (long long)(p - buf_bits); }
   // the rare part of advance(): the buffer has run out, or the stream has (corrupt: the caller checks
   // pos(); what is read from then on is arbitrary but stays inside the tables)
   __device__ __forceinline__ void turn() {
+    const int rel = (int)(p - buf_bits);  // < 0: in the dword below the buffer
+    int wdw = buf_lo + (rel >> 5), avail = rel & 31;
     if (wdw < 0) { underflow = 1; wdw = 0; avail = 0; }
-    if (wdw < buf_lo) fill(wdw + 1);
+    place(wdw, avail);
   }
   // A read in two parts, so that the walk can put the LDS access where it wants it: advance(nb) moves
   // the position below the nb bits and returns the two stream dwords they lie in, bits() cuts them out.
   __device__ __forceinline__ uint2 advance(unsigned nb) {  // nb <= 12; uniform
-    avail -= (int)nb;
-    const int borrow = avail >> 31;
-    wdw += borrow;
-    avail += borrow & 32;
-    if (__builtin_expect(wdw < buf_lo, 0)) turn();
-    const lds_u32 *q = buf + (wdw - buf_lo);
+    p -= nb;
+    if (__builtin_expect(p < buf_bits, 0)) turn();
+    const lds_u32 *q = reinterpret_cast<const lds_u32 *>((p >> 3) & ~3u);
     return make_uint2(q[0], q[1]);
   }
   __device__ __forceinline__ unsigned bits(uint2 win, unsigned nb) const {
-    return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(win.y, win.x, (unsigned)avail), 0u, nb);
+    return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(win.y, win.x, p), 0u, nb);  // (the shift is p mod 32)
   }
 };
 
-// history of the context model: sequence: the context itself; quality: the last three symbols
+// History of the context model, in units of the walk's LDS slots (sizeof(CtxEntry) = 8 bytes): symbols
+// arrive as symbol * 8 (the entry's symbol field as it is), slot() = 8 * context.
+// sequence: the context itself; quality: the last three symbols
 template <class M> struct CtxHist;
 template <> struct CtxHist<SeqModel> {
-  unsigned ctx;
-  __device__ __forceinline__ void start() { ctx = 0xD7u; }  // FSE_Sequence::INITIAL_CONTEXT
-  __device__ __forceinline__ unsigned cur() const { return ctx; }
-  __device__ __forceinline__ unsigned next_if(unsigned s) const { return (ctx >> 2) + ((s & 3u) << 6); }  // addSymUpper
-  __device__ __forceinline__ void push(unsigned s) { ctx = (ctx >> 2) + (s << 6); }
+  unsigned c8;
+  __device__ __forceinline__ void start() { c8 = 0xD7u * 8u; }  // FSE_Sequence::INITIAL_CONTEXT
+  __device__ __forceinline__ unsigned slot() const { return c8; }
+  __device__ __forceinline__ void push(unsigned s8) { c8 = ((c8 >> 2) & ~7u) + (s8 << 6); }  // addSymUpper
 };
 template <> struct CtxHist<QualModel> {
-  unsigned q, q1, q2;  // symbols k-1, k-2, k-3
+  unsigned q, q1, q2;  // 8 * symbols k-1, k-2, k-3
   __device__ __forceinline__ void start() { q = q1 = q2 = 0; }
-  __device__ __forceinline__ unsigned cur() const { return fq_qual_ctx(q, q1, q2); }  // calcContext
-  __device__ __forceinline__ unsigned next_if(unsigned s) const { return fq_qual_ctx(s & 63u, q, q1); }
-  __device__ __forceinline__ void push(unsigned s) { q2 = q1; q1 = q; q = s; }
+  __device__ __forceinline__ unsigned slot() const {  // calcContext (fq_qual_ctx), times 8
+    return ((q1 > q2 ? q1 : q2) << 6) | q | ((unsigned)(q1 == q2) << 15);
+  }
+  __device__ __forceinline__ void push(unsigned s8) { q2 = q1; q1 = q; q = s8; }
 };
 
 // What a stream's walk carries from read to read: the per-context entries (LDS) and the table.
-constexpr uint32_t FQ_ENTRY_PENDING = 0xFFFFFFFFu;
+// Contexts are named by their slot: the byte offset 8 * context of their CtxEntry.
+constexpr uint32_t FQ_ENTRY_PENDING = 0xFFFFFFFFu;  // (nbBits 15: no entry)
+typedef __attribute__((address_space(3))) char lds_char;
 struct Walk {
-  lds_CtxEntry *ce;        // at LDS byte address ce_lds (< 64 KB: the DMA's M0 offset)
+  lds_char *ce;            // CtxEntry[B] at LDS byte address ce_lds (< 64 KB: the DMA's M0 offset)
   unsigned ce_lds;
   const uint32_t *dt;
   __device__ __forceinline__ void init(CtxEntry *lds, const uint32_t *tables) {
-    ce = (lds_CtxEntry *)lds;
+    ce = (lds_char *)(lds_CtxEntry *)lds;
     ce_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ce);
     dt = tables;
   }
-  __device__ __forceinline__ void mark(unsigned c) const { ce[c].entry = FQ_ENTRY_PENDING; }
-  __device__ __forceinline__ uint2 load(unsigned c) const { return make_uint2(ce[c].entry, ce[c].table); }  // (one ds_read_b64)
-  // ce[c].entry <- dt[idx], asynchronously, behind mark(c): lane 0 alone issues (EXEC = 1; the walk
-  // runs with all 64 lanes); the LDS destination of an LDS-DMA load is M0 + 4 * lane id.
+  __device__ __forceinline__ lds_CtxEntry *at(unsigned slot) const { return reinterpret_cast<lds_CtxEntry *>(ce + slot); }
+  __device__ __forceinline__ void mark(unsigned slot) const { at(slot)->entry = FQ_ENTRY_PENDING; }
+  __device__ __forceinline__ uint2 load(unsigned slot) const { return make_uint2(at(slot)->entry, at(slot)->table); }  // (one ds_read_b64)
+  // entry of `slot` <- the dword at byte offset `off` of the tables, asynchronously, behind
+  // mark(slot): lane 0 alone issues (EXEC = 1; the walk runs with all 64 lanes); the LDS destination
+  // of an LDS-DMA load is M0 + 4 * lane id.
   // lgkmcnt(1): LDS operations complete in issue order and the load() of the next entry was issued
   // behind the mark (the compiler cannot swap the two: they may alias), so at most that load, or
   // one behind it, is still on its way -- the mark has landed.
   // M0 is not restored: nothing else in these kernels uses it (no other LDS-DMA, no movrel).
-  __device__ __forceinline__ void refill(unsigned c, unsigned idx) const {
-    const unsigned off = idx * 4u;  // < 2^27 entries
-    const unsigned dst = __builtin_amdgcn_readfirstlane(ce_lds + c * (unsigned)sizeof(CtxEntry));
+  __device__ __forceinline__ void refill(unsigned slot, unsigned off) const {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(ce_lds + slot);
     asm volatile("s_waitcnt lgkmcnt(1)\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 1\n\t"
                  "global_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
                  : : "v"(off), "s"(dt), "s"(dst) : "memory");
   }
-  // entry of context c from what load(c) returned; a pending entry is waited for
-  __device__ __forceinline__ uint32_t take(unsigned c, uint2 e) const {
+  // entry of the context from what load(slot) returned; a pending entry is waited for
+  __device__ __forceinline__ uint32_t take(unsigned slot, uint2 e) const {
     uint32_t entry = __builtin_amdgcn_readfirstlane(e.x);
     if (__builtin_expect(entry == FQ_ENTRY_PENDING, 0)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      entry = __builtin_amdgcn_readfirstlane(ce[c].entry);
+      entry = __builtin_amdgcn_readfirstlane(at(slot)->entry);
     }
     return entry;
   }
@@ -208,27 +217,27 @@ template <class M>
 __device__ __forceinline__ void walk_positions(Walk &wk, LdsBits &br, g_u8 *out, unsigned i0, unsigned i1, CtxHist<M> h) {
   if (i0 >= i1) return;
   const unsigned lane = threadIdx.x;
-  unsigned ctx = h.cur();
-  uint2 e = wk.load(ctx);
-  uint32_t cur = wk.take(ctx, e);
+  unsigned slot = h.slot();
+  uint2 e = wk.load(slot);
+  uint32_t cur = wk.take(slot, e);
   unsigned keep = 0, acc = 0;
   // one symbol; j = its byte in acc.  Order: the stream dwords of this symbol's bits are asked for
   // first (their address needs nbBits only), then the next context's entry (the chain); the refill's
-  // arithmetic runs while that entry is on its way.
+  // arithmetic runs while that entry is on its way.  Entry fields: FQ_DENTRY (fqgpu_internal.h).
   auto step = [&](unsigned j) {
-    const unsigned nb = cur >> 24;
+    const unsigned nb = (cur >> 9) & 15u;
     const uint2 win = br.advance(nb);
-    const unsigned sym = (cur >> 16) & (unsigned)(M::A - 1);
-    h.push(sym);
-    const unsigned nctx = h.cur();
-    wk.mark(ctx);
-    const uint2 ne = wk.load(nctx);
-    const unsigned idx = (cur & 0xFFFFu) + e.y + br.bits(win, nb);  // (e.y, the table, stays in its vector register)
-    acc |= sym << (8u * j);
-    wk.refill(ctx, idx);
-    ctx = nctx;
+    const unsigned s8 = cur & (unsigned)((M::A - 1) << 3);
+    h.push(s8);
+    const unsigned nslot = h.slot();
+    wk.mark(slot);
+    const uint2 ne = wk.load(nslot);
+    const unsigned off = (cur >> 16) + ((br.bits(win, nb) << 2) + e.y);  // (e.y, the table's byte offset, stays in its vector register)
+    acc |= (s8 >> 3) << (8u * j);
+    wk.refill(slot, off);
+    slot = nslot;
     e = ne;
-    cur = wk.take(ctx, e);  // (one too many at the end of a read: the next read starts from another context)
+    cur = wk.take(slot, e);  // (one too many at the end of a read: the next read starts from another context)
   };
   g_u8 *o = out + i0;
   const unsigned n = i1 - i0;
@@ -272,7 +281,7 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, CtxEntry *ce,
     const unsigned lg = tab.logs[c];
     const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
     const uint32_t table = tab.dt_off[c] + 1u;  // behind the table's header word
-    ce[c].table = table;
+    ce[c].table = table * 4u;
     ce[c].entry = tab.dt[table + peek_bits(w, lo, lg)];
   }
   __syncthreads();
@@ -330,7 +339,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     for (unsigned c = lane; c < B; c += 64) {
       const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
       const uint32_t table = tab.dt_off[c] + 1u;
-      ce[c].table = table;
+      ce[c].table = table * 4u;
       ce[c].entry = tab.dt[table + peek_bits(w, lo, tab.logs[c])];
     }
     pos = p0 - (long long)sum_logs;
@@ -340,7 +349,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     const uint16_t *st = reinterpret_cast<const uint16_t *>(snap + FQ_INDEX_SNAP_HEAD);
     for (unsigned c = lane; c < B; c += 64) {
       const uint32_t table = tab.dt_off[c] + 1u;
-      ce[c].table = table;
+      ce[c].table = table * 4u;
       ce[c].entry = tab.dt[table + ((unsigned)st[c] & ((1u << tab.logs[c]) - 1u))];  // a damaged index must not leave the table
     }
     pos = (long long)*reinterpret_cast<const unsigned long long *>(snap);
@@ -371,13 +380,13 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
       if constexpr (M::STREAM == 0) {
         for (int b = 3; b >= 0; b--) {
           const unsigned ch = (prev >> (8 * b)) & 0xFFu;
-          if (ch != 0xFFu) h.push(fq_base_code(ch));
+          if (ch != 0xFFu) h.push(fq_base_code(ch) * 8u);
         }
       } else {
         const unsigned a = prev & 0xFFu, b = (prev >> 8) & 0xFFu, c = (prev >> 16) & 0xFFu;
-        h.q = a != 0xFFu ? (a - 33u) & 63u : 0u;
-        h.q1 = b != 0xFFu ? (b - 33u) & 63u : 0u;
-        h.q2 = c != 0xFFu ? (c - 33u) & 63u : 0u;
+        h.q = a != 0xFFu ? ((a - 33u) & 63u) * 8u : 0u;
+        h.q1 = b != 0xFFu ? ((b - 33u) & 63u) * 8u : 0u;
+        h.q2 = c != 0xFFu ? ((c - 33u) & 63u) * 8u : 0u;
       }
     }
     walk_positions<M>(wk, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), i0, i1, h);

@@ -26,6 +26,13 @@ struct QualModel {
 };
 
 // Device-side tables of one stream, built once per handle.
+// Decoder entry (one per state, behind the table's zstd header word): the fields of zstd's FSE_decode_t
+// arranged for the decode walk -- [31:16] newState * 4 (byte offset inside the table), [12:9] nbBits,
+// [8:3] symbol (= symbol * 8, the stride of the walk's per-context LDS slots).  fqgpu_ctx_dump_tables
+// hands out zstd's layout {u16 newState; u8 symbol; u8 nbBits}.
+#define FQ_DENTRY(new_state, sym, nb) ((((uint32_t)(new_state)) << 18) | ((uint32_t)(nb) << 9) | ((uint32_t)(sym) << 3))
+#define FQ_DENTRY_TO_ZSTD(w) ((((uint32_t)(w)) >> 18) | (((((uint32_t)(w)) >> 3) & 63u) << 16) | (((((uint32_t)(w)) >> 9) & 15u) << 24))
+
 struct DevTables {
   int16_t *norm = nullptr;      // [B][A]
   uint32_t *logs = nullptr;     // [B]

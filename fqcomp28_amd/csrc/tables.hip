@@ -367,7 +367,7 @@ k_build_tables(const int16_t *__restrict__ norm, const uint32_t *__restrict__ lo
       const unsigned ns = cumul[s + 1] - cumul[s];
       const unsigned x = ns + r;
       const unsigned nb = t - hb32(x);
-      dt[1 + u] = (((x << nb) - size) & 0xFFFFu) | (s << 16) | (nb << 24);
+      dt[1 + u] = FQ_DENTRY(((x << nb) - size) & 0x3FFFu, s, nb);
     }
     __syncthreads();
   }
