@@ -35,7 +35,7 @@ def last_json(path):
 
 # bench.py's span labels -> the kernel(s) launched inside them
 SPAN_KERNELS = {
-    "seq.tile_hist": ["k_tile_hist<SeqModel>"], "qual.tile_hist": ["k_tile_hist<QualModel>"],
+    "tile_hist2": ["k_tile_hist2"],
     "seq.scatter": ["k_tile_partition<SeqModel>"], "qual.scatter": ["k_tile_partition<QualModel>"],
     "seq.setfunc": ["k_seq_setfunc<32u, true>"], "seq.chains": ["k_seq_emit"], "seq.resolve": ["k_seq_resolve"],
     "qual.walk1": ["k_seg_walk<QualModel, 1>"], "qual.walk2": ["k_seg_walk<QualModel, 2>"],
@@ -68,7 +68,7 @@ def agg(path):
 
 fa = agg(newest(R + "gpurun_out/r02_pmc_f/**/*counter_collection.csv"))
 wa = agg(newest(R + "gpurun_out/r02_pmc_w/**/*counter_collection.csv"))
-skip = ("k_hist", "k_build", "k_normalize", "k_fill", "k_log", "k_reset", "k_probe")
+skip = ("k_hist_", "k_build", "k_normalize", "k_fill", "k_log", "k_reset", "k_probe")
 out = []
 for n in sorted(fa, key=lambda k: -(fa[k][1] * 2 + wa.get(k, [0, 0])[1])):
     c = fa[n][0]
