@@ -428,6 +428,9 @@ extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
     for (hipEvent_t e : ctx->timer->pool) (void)hipEventDestroy(e);
     delete ctx->timer;
   }
+  if (ctx->dec_stream2) (void)hipStreamDestroy(ctx->dec_stream2);
+  if (ctx->dec_fork) (void)hipEventDestroy(ctx->dec_fork);
+  if (ctx->dec_join) (void)hipEventDestroy(ctx->dec_join);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

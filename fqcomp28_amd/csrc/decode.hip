@@ -397,13 +397,16 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
   if (lane == 0 && br.pos() != pos_end) res->corrupt = 1;
 }
 
+// one workgroup per stride; M's chunks only: the two streams are launched separately because their
+// LDS footprints differ by a factor of 16 (quality: 64 KB of entries, two workgroups per CU; sequence: 2 KB)
+// -- in one kernel the sequence strides would take the quality strides' places
+template <class M>
 __global__ void __launch_bounds__(64)
-k_decode_chunks(const DecJob *__restrict__ jobs, const DecChunk *__restrict__ chunks, TabView seq_tab, TabView qual_tab) {
-  __shared__ CtxEntry ce[QualModel::B];
+k_decode_chunks(const DecJob *__restrict__ jobs, const DecChunk *__restrict__ chunks, TabView tab) {
+  __shared__ CtxEntry ce[M::B];
   __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
   const DecChunk ch = chunks[blockIdx.x];
-  if (ch.stream) decode_chunk<QualModel>(jobs[ch.job], ch.chunk, qual_tab, ce, bitbuf);
-  else decode_chunk<SeqModel>(jobs[ch.job], ch.chunk, seq_tab, ce, bitbuf);
+  decode_chunk<M>(jobs[ch.job], ch.chunk, tab, ce, bitbuf);
 }
 
 // record lengths of one block, for the encode index of the first symbol of every record
@@ -413,10 +416,19 @@ k_lens_of(const fqgpu_rec *__restrict__ recs, unsigned n, uint32_t *__restrict__
   if (r < n) lens32[r] = recs[r].len;
 }
 
-// grid = 2 * n_blocks: the quality streams (longer chains, MB-scale DTables) are
-// dispatched first, the sequence streams behind them
+// one workgroup per block: stream M of every block of the batch
+template <class M>
 __global__ void __launch_bounds__(64)
-k_decode(const DecJob *__restrict__ jobs, unsigned n_blocks, TabView seq_tab, TabView qual_tab) {
+k_decode(const DecJob *__restrict__ jobs, TabView tab) {
+  __shared__ CtxEntry ce[M::B];
+  __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
+  decode_stream<M>(jobs[blockIdx.x], tab, ce, bitbuf);
+}
+// both streams in one launch (grid = 2 * n_blocks, the quality streams first): for batches whose
+// chains all find a place at once (two workgroups of 66 KB per CU) -- then the placement of one
+// launch, a quality and a sequence chain per CU, is the better one (256 x 1 MiB blocks: 5.0 against 4.6 GB/s)
+__global__ void __launch_bounds__(64)
+k_decode_both(const DecJob *__restrict__ jobs, unsigned n_blocks, TabView seq_tab, TabView qual_tab) {
   __shared__ CtxEntry ce[QualModel::B];
   __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
   if (blockIdx.x < n_blocks) decode_stream<QualModel>(jobs[blockIdx.x], qual_tab, ce, bitbuf);
@@ -504,7 +516,7 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks_in, size_t n_bl
     if (snaps_of(blocks_in[i], 0) && snaps_of(blocks_in[i], 1)) blocks.push_back(blocks_in[i]);
 
   std::vector<DecJob> host(n_blocks);
-  std::vector<DecChunk> chunks;
+  std::vector<DecChunk> chunks, seq_chunks;  // quality strides | sequence strides
   size_t r_tot = 0, r_max = 0, rs_tot = 0;
   for (size_t i = 0; i < n_blocks; i++) {
     const fqgpu_dblock *b = blocks[i];
@@ -524,6 +536,7 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks_in, size_t n_bl
     if (i >= n_plain) rs_tot += b->n_recs + 1;
   }
   int rc;
+  size_t n_qual_chunks = 0;
   if ((rc = ctx->dec_desc.reserve(n_blocks * sizeof(DecJob)))) return rc;
   if ((rc = ctx->n_cnt32.reserve((r_tot + 1) * 4))) return rc;
   if ((rc = ctx->n_off.reserve((r_tot + 1) * 4))) return rc;
@@ -541,9 +554,11 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks_in, size_t n_bl
       hipLaunchKernelGGL(k_lens_of, dim3((unsigned)((b->n_recs + 255) / 256)), dim3(256), 0, st, b->recs, (unsigned)b->n_recs,
                          ctx->n_cnt32.as<uint32_t>());
       if ((rc = fq_scan_u32_to_u32(st, ctx->n_cnt32.as<uint32_t>(), b->n_recs, rs, ctx->scan_tmp))) return rc;
-      for (int s = 1; s >= 0; s--)  // quality strides first: they are the longer ones
-        for (size_t k = snaps_of(b, s) + 1; k-- > 0;) chunks.push_back(DecChunk{(unsigned)i, (unsigned)s, (unsigned)k});
+      for (size_t k = snaps_of(b, 1) + 1; k-- > 0;) chunks.push_back(DecChunk{(unsigned)i, 1u, (unsigned)k});
+      for (size_t k = snaps_of(b, 0) + 1; k-- > 0;) seq_chunks.push_back(DecChunk{(unsigned)i, 0u, (unsigned)k});
     }
+    n_qual_chunks = chunks.size();
+    chunks.insert(chunks.end(), seq_chunks.begin(), seq_chunks.end());
     if ((rc = ctx->dec_chunks.reserve(chunks.size() * sizeof(DecChunk)))) return rc;
     FQ_HIP(hipMemcpyAsync(ctx->dec_chunks.p, chunks.data(), chunks.size() * sizeof(DecChunk), hipMemcpyHostToDevice, st));
   }
@@ -556,11 +571,28 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks_in, size_t n_bl
     FQ_HIP(hipMemsetAsync(blocks[i]->result, 0, sizeof(BlockResult), st));
   TabView ts = {ctx->tab[0].logs, ctx->tab[0].log_prefix, ctx->tab[0].dt, ctx->tab[0].dt_off};
   TabView tq = {ctx->tab[1].logs, ctx->tab[1].log_prefix, ctx->tab[1].dt, ctx->tab[1].dt_off};
+  // the sequence streams run beside the quality streams on a second stream
+  if (!ctx->dec_stream2) {
+    FQ_HIP(hipStreamCreateWithFlags(&ctx->dec_stream2, hipStreamNonBlocking));
+    FQ_HIP(hipEventCreateWithFlags(&ctx->dec_fork, hipEventDisableTiming));
+    FQ_HIP(hipEventCreateWithFlags(&ctx->dec_join, hipEventDisableTiming));
+  }
+  hipStream_t st2 = ctx->dec_stream2;
   fq_timer_span_begin(ctx, "decode", st);
-  if (n_plain)
-    hipLaunchKernelGGL(k_decode, dim3((unsigned)(2 * n_plain)), dim3(64), 0, st, jobs, (unsigned)n_plain, ts, tq);
-  if (!chunks.empty())
-    hipLaunchKernelGGL(k_decode_chunks, dim3((unsigned)chunks.size()), dim3(64), 0, st, jobs, ctx->dec_chunks.as<DecChunk>(), ts, tq);
+  FQ_HIP(hipEventRecord(ctx->dec_fork, st));
+  FQ_HIP(hipStreamWaitEvent(st2, ctx->dec_fork, 0));
+  const DecChunk *dch = ctx->dec_chunks.as<DecChunk>();
+  if (n_plain && 2 * n_plain <= 2 * (size_t)ctx->n_cus) {
+    hipLaunchKernelGGL(k_decode_both, dim3((unsigned)(2 * n_plain)), dim3(64), 0, st, jobs, (unsigned)n_plain, ts, tq);
+  } else if (n_plain) {
+    hipLaunchKernelGGL(k_decode<QualModel>, dim3((unsigned)n_plain), dim3(64), 0, st, jobs, tq);
+    hipLaunchKernelGGL(k_decode<SeqModel>, dim3((unsigned)n_plain), dim3(64), 0, st2, jobs, ts);
+  }
+  if (n_qual_chunks) hipLaunchKernelGGL(k_decode_chunks<QualModel>, dim3((unsigned)n_qual_chunks), dim3(64), 0, st, jobs, dch, tq);
+  if (chunks.size() > n_qual_chunks)
+    hipLaunchKernelGGL(k_decode_chunks<SeqModel>, dim3((unsigned)(chunks.size() - n_qual_chunks)), dim3(64), 0, st2, jobs, dch + n_qual_chunks, ts);
+  FQ_HIP(hipEventRecord(ctx->dec_join, st2));
+  FQ_HIP(hipStreamWaitEvent(st, ctx->dec_join, 0));
   fq_timer_span_end(ctx, st);
   fq_timer_span_begin(ctx, "npatch", st);
   const unsigned gx = (unsigned)min((r_max + 255) / 256, (size_t)4096);

@@ -140,6 +140,8 @@ struct EncLane {
 struct fqgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;  // uploads, decode
+  hipStream_t dec_stream2 = nullptr;  // decode: the sequence streams, beside the quality streams on `stream`
+  hipEvent_t dec_fork = nullptr, dec_join = nullptr;
   DevTables tab[2];
   unsigned seg_len = 0;          // segment of the generic chain kernels (0 = by block size: 1024..4096)
   int seq_generic = 0;           // 1: sequence stream also uses the reset-cut kernel
