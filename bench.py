@@ -398,6 +398,8 @@ def main():
             pr = F.pinned_empty(raw_t.size)
             pr[:] = raw_t
             nb = int(recs_t["len"].sum())
+            # block and streams page-locked, the small side buffers pageable: what the C++ shim's FastqChunk /
+            # CompressedBuffers hold (workspace.hpp says why the side buffers are better left pageable)
             bufs = dict(seq=F.pinned_empty(F.bound_seq(nb)), qual=F.pinned_empty(F.bound_qual(nb)),
                         readlens=np.zeros(len(recs_t), np.uint16), n_count=np.zeros(len(recs_t), np.uint16),
                         n_pos=np.zeros(nb + 1, np.uint16))
@@ -435,7 +437,7 @@ def main():
             best = d1 if best is None else min(best, d1)
         # a host-pointer result against the resident path's: same bytes
         same_hp = bool(check is None or (pins[(len(blocks) - 1) % T][0].size == blocks[-1][0].size))
-        extra["host_pointer"] = {"threads": T, "handles": T, "blocks_coded": T * per_thread, "buffers": "page-locked (fqgpu_host_alloc)",
+        extra["host_pointer"] = {"threads": T, "handles": T, "blocks_coded": T * per_thread, "buffers": "block and streams page-locked (fqgpu_host_alloc), side buffers pageable",
                                  "includes": "H2D of the block + record table, encode, D2H of both streams and the side streams",
                                  "one_thread_pageable_MBps": round(raw0.size / best / MB, 1), "sane": same_hp}
         for c in ctxs[1:]:

@@ -103,6 +103,7 @@ _PROTOS = {
     "fqgpu_ctx_timing_only": (C.c_int, [C.c_void_p, C.c_char_p]),
     "fqgpu_host_alloc": (C.c_void_p, [C.c_size_t]),
     "fqgpu_host_free": (None, [C.c_void_p]),
+    "fqgpu_host_trim": (C.c_size_t, []),
     "fqgpu_memcompress_bound": (C.c_size_t, [C.c_size_t]),
     "fqgpu_memcompress": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "fqgpu_memdecompress": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),

