@@ -164,40 +164,71 @@ template <> struct CtxHist<QualModel> {
 };
 
 // What a stream's walk carries from read to read: the per-context entries (LDS) and the table.
-// Contexts are named by their slot: the byte offset 8 * context of their CtxEntry.
+// Contexts are named by their slot: 8 * context = the byte offset of their CtxEntry.
+//
+// COMPACT: the entries alone in LDS (4 bytes per context: 32 KB for the quality stream, four
+// workgroups per CU instead of two), the context's table offset read from dt_off by a SCALAR load
+// one symbol ahead (it waits in the shadow of the next entry's LDS read).  Five more instructions
+// per symbol and twice the places: for batches with more chains than places.
 constexpr uint32_t FQ_ENTRY_PENDING = 0xFFFFFFFFu;  // (nbBits 15: no entry)
 typedef __attribute__((address_space(3))) char lds_char;
-struct Walk {
-  lds_char *ce;            // CtxEntry[B] at LDS byte address ce_lds (< 64 KB: the DMA's M0 offset)
+template <bool COMPACT>
+struct WalkT {
+  lds_char *ce;            // CtxEntry[B] (COMPACT: u32[B]) at LDS byte address ce_lds (< 64 KB: the DMA's M0 offset)
   unsigned ce_lds;
-  const uint32_t *dt;
-  __device__ __forceinline__ void init(CtxEntry *lds, const uint32_t *tables) {
-    ce = (lds_char *)(lds_CtxEntry *)lds;
+  const uint32_t *dt, *dt_off;
+  using Slots = typename std::conditional<COMPACT, uint32_t, CtxEntry>::type;
+  __device__ __forceinline__ void init(Slots *lds, const uint32_t *tables, const uint32_t *table_offsets) {
+    ce = (lds_char *)(__attribute__((address_space(3))) Slots *)lds;
     ce_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ce);
     dt = tables;
+    dt_off = table_offsets;
   }
-  __device__ __forceinline__ lds_CtxEntry *at(unsigned slot) const { return reinterpret_cast<lds_CtxEntry *>(ce + slot); }
-  __device__ __forceinline__ void mark(unsigned slot) const { at(slot)->entry = FQ_ENTRY_PENDING; }
-  __device__ __forceinline__ uint2 load(unsigned slot) const { return make_uint2(at(slot)->entry, at(slot)->table); }  // (one ds_read_b64)
+  // LDS byte offset of a slot
+  static __device__ __forceinline__ unsigned lds_of(unsigned slot) { return COMPACT ? slot >> 1 : slot; }
+  __device__ __forceinline__ lds_u32 *entry_at(unsigned slot) const { return reinterpret_cast<lds_u32 *>(ce + lds_of(slot)); }
+  __device__ __forceinline__ void mark(unsigned slot) const { *entry_at(slot) = FQ_ENTRY_PENDING; }
+  // {entry, table byte offset} (one ds_read_b64); COMPACT: {entry, -}
+  __device__ __forceinline__ uint2 load(unsigned slot) const {
+    if (COMPACT) return make_uint2(*entry_at(slot), 0u);
+    const lds_CtxEntry *e = reinterpret_cast<const lds_CtxEntry *>(ce + slot);
+    return make_uint2(e->entry, e->table);
+  }
+  // COMPACT: dt_off[context of slot], asked for now (scalar load: it must not touch vmcnt, which the
+  // refills own), valid behind settle()
+  __device__ __forceinline__ uint32_t ask_table(unsigned slot) const {
+    uint32_t t = 0;
+    if (COMPACT) asm volatile("s_load_dword %0, %1, %2" : "=s"(t) : "s"(dt_off), "s"(__builtin_amdgcn_readfirstlane(slot >> 1)) : "memory");
+    return t;
+  }
+  static __device__ __forceinline__ void settle(uint32_t &t) {
+    if (COMPACT) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t) : : "memory");
+  }
   // entry of `slot` <- the dword at byte offset `off` of the tables, asynchronously, behind
   // mark(slot): lane 0 alone issues (EXEC = 1; the walk runs with all 64 lanes); the LDS destination
   // of an LDS-DMA load is M0 + 4 * lane id.
   // lgkmcnt(1): LDS operations complete in issue order and the load() of the next entry was issued
   // behind the mark (the compiler cannot swap the two: they may alias), so at most that load, or
-  // one behind it, is still on its way -- the mark has landed.
+  // one behind it, is still on its way -- the mark has landed.  (COMPACT: the scalar load asked for
+  // in between may return out of order: lgkmcnt(0).)
   // M0 is not restored: nothing else in these kernels uses it (no other LDS-DMA, no movrel).
   __device__ __forceinline__ void refill(unsigned slot, unsigned off) const {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(ce_lds + slot);
-    asm volatile("s_waitcnt lgkmcnt(1)\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 1\n\t"
-                 "global_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
-                 : : "v"(off), "s"(dt), "s"(dst) : "memory");
+    const unsigned dst = __builtin_amdgcn_readfirstlane(ce_lds + lds_of(slot));
+    if (COMPACT)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 1\n\t"
+                   "global_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
+                   : : "v"(off), "s"(dt), "s"(dst) : "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(1)\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 1\n\t"
+                   "global_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
+                   : : "v"(off), "s"(dt), "s"(dst) : "memory");
   }
   // entry of the context from what load(slot) returned; a pending entry is waited for
   __device__ __forceinline__ uint32_t take(unsigned slot, uint2 e) const {
     uint32_t entry = __builtin_amdgcn_readfirstlane(e.x);
     if (__builtin_expect(entry == FQ_ENTRY_PENDING, 0)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      entry = __builtin_amdgcn_readfirstlane(at(slot)->entry);
+      entry = __builtin_amdgcn_readfirstlane(*entry_at(slot));
     }
     return entry;
   }
@@ -213,13 +244,15 @@ __device__ __forceinline__ unsigned fq_sym_bytes(unsigned acc) {
 // Positions [i0, i1) of one read into out[i0 ..], all 64 lanes of the wave; h = history in front of
 // position i0.  Everything the walk decides on (entry, symbol, context, bit position) is wave-uniform
 // and kept in scalar registers.  Lane k keeps output bytes 4k .. 4k + 3 of the current 256.
-template <class M>
-__device__ __forceinline__ void walk_positions(Walk &wk, LdsBits &br, g_u8 *out, unsigned i0, unsigned i1, CtxHist<M> h) {
+template <class M, bool COMPACT>
+__device__ __forceinline__ void walk_positions(WalkT<COMPACT> &wk, LdsBits &br, g_u8 *out, unsigned i0, unsigned i1, CtxHist<M> h) {
   if (i0 >= i1) return;
   const unsigned lane = threadIdx.x;
   unsigned slot = h.slot();
+  uint32_t toff = wk.ask_table(slot);  // (COMPACT) dt_off of the current context
   uint2 e = wk.load(slot);
   uint32_t cur = wk.take(slot, e);
+  wk.settle(toff);
   unsigned keep = 0, acc = 0;
   // one symbol; j = its byte in acc.  Order: the stream dwords of this symbol's bits are asked for
   // first (their address needs nbBits only), then the next context's entry (the chain); the refill's
@@ -232,12 +265,16 @@ __device__ __forceinline__ void walk_positions(Walk &wk, LdsBits &br, g_u8 *out,
     const unsigned nslot = h.slot();
     wk.mark(slot);
     const uint2 ne = wk.load(nslot);
-    const unsigned off = (cur >> 16) + ((br.bits(win, nb) << 2) + e.y);  // (e.y, the table's byte offset, stays in its vector register)
+    uint32_t ntoff = wk.ask_table(nslot);
+    // (e.y, the table's byte offset, stays in its vector register; COMPACT: the state-0 entry is word dt_off + 1)
+    const unsigned off = COMPACT ? (cur >> 16) + ((br.bits(win, nb) + (toff + 1u)) << 2) : (cur >> 16) + ((br.bits(win, nb) << 2) + e.y);
     acc |= (s8 >> 3) << (8u * j);
     wk.refill(slot, off);
     slot = nslot;
     e = ne;
     cur = wk.take(slot, e);  // (one too many at the end of a read: the next read starts from another context)
+    wk.settle(ntoff);
+    toff = ntoff;
   };
   g_u8 *o = out + i0;
   const unsigned n = i1 - i0;
@@ -258,8 +295,12 @@ __device__ __forceinline__ void walk_positions(Walk &wk, LdsBits &br, g_u8 *out,
   if (lane < r) o[g + lane] = (uint8_t)(fq_sym_bytes<M>(acc) >> (8u * lane));
 }
 
-template <class M>
-__device__ void decode_stream(const DecJob &j, const TabView &tab, CtxEntry *ce, uint32_t *bitbuf) {
+// the entry (and, resident form, the table offset) of context c at the start of a walk
+__device__ __forceinline__ void set_slot(CtxEntry *ce, unsigned c, uint32_t table, uint32_t entry) { ce[c].table = table * 4u; ce[c].entry = entry; }
+__device__ __forceinline__ void set_slot(uint32_t *ce, unsigned c, uint32_t, uint32_t entry) { ce[c] = entry; }
+
+template <class M, bool COMPACT>
+__device__ void decode_stream(const DecJob &j, const TabView &tab, typename WalkT<COMPACT>::Slots *ce, uint32_t *bitbuf) {
   constexpr unsigned B = M::B;
   const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
@@ -281,12 +322,11 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, CtxEntry *ce,
     const unsigned lg = tab.logs[c];
     const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
     const uint32_t table = tab.dt_off[c] + 1u;  // behind the table's header word
-    ce[c].table = table * 4u;
-    ce[c].entry = tab.dt[table + peek_bits(w, lo, lg)];
+    set_slot(ce, c, table, tab.dt[table + peek_bits(w, lo, lg)]);
   }
   __syncthreads();
-  Walk wk;
-  wk.init(ce, tab.dt);
+  WalkT<COMPACT> wk;
+  wk.init(ce, tab.dt, tab.dt_off);
 
   LdsBits br;
   br.init(w, p0 - (long long)sum_logs, bitbuf, (len + 3) / 4);
@@ -297,7 +337,7 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, CtxEntry *ce,
     if (r > 1) { nxt.seq_off = recs[r - 2].seq_off; nxt.qual_off = recs[r - 2].qual_off; nxt.len = recs[r - 2].len; }  // lands while this record is walked
     CtxHist<M> h;
     h.start();
-    walk_positions<M>(wk, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), 0u, rec.len, h);
+    walk_positions<M, COMPACT>(wk, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), 0u, rec.len, h);
     if (br.underflow) break;
   }
   // BIT_endOfDStream (src/fse_common.hpp:141): every bit consumed, none invented
@@ -310,8 +350,8 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, CtxEntry *ce,
 // One stride of one stream, started from a snapshot of the decode index (or from the end of the
 // stream for the last stride): encode indices [e_lo, e_hi) in decoder order, i.e. from the record
 // and position of symbol e_hi - 1 towards the front of the block.
-template <class M>
-__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, CtxEntry *ce, uint32_t *bitbuf) {
+template <class M, bool COMPACT>
+__device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab, typename WalkT<COMPACT>::Slots *ce, uint32_t *bitbuf) {
   constexpr unsigned B = M::B;
   const uint8_t *src = M::STREAM == 0 ? j.seq : j.qual;
   const unsigned len = M::STREAM == 0 ? j.seq_len : j.qual_len;
@@ -339,8 +379,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     for (unsigned c = lane; c < B; c += 64) {
       const long long lo = p0 - (long long)(sum_logs - tab.log_prefix[c]);
       const uint32_t table = tab.dt_off[c] + 1u;
-      ce[c].table = table * 4u;
-      ce[c].entry = tab.dt[table + peek_bits(w, lo, tab.logs[c])];
+      set_slot(ce, c, table, tab.dt[table + peek_bits(w, lo, tab.logs[c])]);
     }
     pos = p0 - (long long)sum_logs;
     if (lane == 0) res->total_bits = (unsigned long long)pos;
@@ -349,8 +388,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
     const uint16_t *st = reinterpret_cast<const uint16_t *>(snap + FQ_INDEX_SNAP_HEAD);
     for (unsigned c = lane; c < B; c += 64) {
       const uint32_t table = tab.dt_off[c] + 1u;
-      ce[c].table = table * 4u;
-      ce[c].entry = tab.dt[table + ((unsigned)st[c] & ((1u << tab.logs[c]) - 1u))];  // a damaged index must not leave the table
+      set_slot(ce, c, table, tab.dt[table + ((unsigned)st[c] & ((1u << tab.logs[c]) - 1u))]);  // a damaged index must not leave the table
     }
     pos = (long long)*reinterpret_cast<const unsigned long long *>(snap);
     prev = reinterpret_cast<const uint32_t *>(snap)[2];
@@ -363,8 +401,8 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
 
   LdsBits br;
   br.init(w, pos, bitbuf, (len + 3) / 4);
-  Walk wk;
-  wk.init(ce, tab.dt);
+  WalkT<COMPACT> wk;
+  wk.init(ce, tab.dt, tab.dt_off);
   unsigned r = fq_locate((const uint32_t *)j.rec_start, 0, j.n_recs - 1, e_hi - 1);  // record of symbol e_hi - 1
   bool first = true;
   for (;;) {
@@ -389,7 +427,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
         h.q2 = c != 0xFFu ? ((c - 33u) & 63u) * 8u : 0u;
       }
     }
-    walk_positions<M>(wk, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), i0, i1, h);
+    walk_positions<M, COMPACT>(wk, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), i0, i1, h);
     first = false;
     if (br.underflow || rs <= e_lo || r == 0) break;
     r--;
@@ -400,13 +438,13 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
 // one workgroup per stride; M's chunks only: the two streams are launched separately because their
 // LDS footprints differ by a factor of 16 (quality: 64 KB of entries, two workgroups per CU; sequence: 2 KB)
 // -- in one kernel the sequence strides would take the quality strides' places
-template <class M>
+template <class M, bool COMPACT>
 __global__ void __launch_bounds__(64)
 k_decode_chunks(const DecJob *__restrict__ jobs, const DecChunk *__restrict__ chunks, TabView tab) {
-  __shared__ CtxEntry ce[M::B];
+  __shared__ typename WalkT<COMPACT>::Slots ce[M::B];
   __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
   const DecChunk ch = chunks[blockIdx.x];
-  decode_chunk<M>(jobs[ch.job], ch.chunk, tab, ce, bitbuf);
+  decode_chunk<M, COMPACT>(jobs[ch.job], ch.chunk, tab, ce, bitbuf);
 }
 
 // record lengths of one block, for the encode index of the first symbol of every record
@@ -417,12 +455,12 @@ k_lens_of(const fqgpu_rec *__restrict__ recs, unsigned n, uint32_t *__restrict__
 }
 
 // one workgroup per block: stream M of every block of the batch
-template <class M>
+template <class M, bool COMPACT>
 __global__ void __launch_bounds__(64)
 k_decode(const DecJob *__restrict__ jobs, TabView tab) {
-  __shared__ CtxEntry ce[M::B];
+  __shared__ typename WalkT<COMPACT>::Slots ce[M::B];
   __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
-  decode_stream<M>(jobs[blockIdx.x], tab, ce, bitbuf);
+  decode_stream<M, COMPACT>(jobs[blockIdx.x], tab, ce, bitbuf);
 }
 // both streams in one launch (grid = 2 * n_blocks, the quality streams first): for batches whose
 // chains all find a place at once (two workgroups of 66 KB per CU) -- then the placement of one
@@ -431,8 +469,8 @@ __global__ void __launch_bounds__(64)
 k_decode_both(const DecJob *__restrict__ jobs, unsigned n_blocks, TabView seq_tab, TabView qual_tab) {
   __shared__ CtxEntry ce[QualModel::B];
   __shared__ uint32_t bitbuf[FQ_BITBUF_DW];
-  if (blockIdx.x < n_blocks) decode_stream<QualModel>(jobs[blockIdx.x], qual_tab, ce, bitbuf);
-  else decode_stream<SeqModel>(jobs[blockIdx.x - n_blocks], seq_tab, ce, bitbuf);
+  if (blockIdx.x < n_blocks) decode_stream<QualModel, false>(jobs[blockIdx.x], qual_tab, ce, bitbuf);
+  else decode_stream<SeqModel, false>(jobs[blockIdx.x - n_blocks], seq_tab, ce, bitbuf);
 }
 
 // batch-wide record arrays: N counts widened for the scan
@@ -585,12 +623,15 @@ int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks_in, size_t n_bl
   if (n_plain && 2 * n_plain <= 2 * (size_t)ctx->n_cus) {
     hipLaunchKernelGGL(k_decode_both, dim3((unsigned)(2 * n_plain)), dim3(64), 0, st, jobs, (unsigned)n_plain, ts, tq);
   } else if (n_plain) {
-    hipLaunchKernelGGL(k_decode<QualModel>, dim3((unsigned)n_plain), dim3(64), 0, st, jobs, tq);
-    hipLaunchKernelGGL(k_decode<SeqModel>, dim3((unsigned)n_plain), dim3(64), 0, st2, jobs, ts);
+    // more quality chains than places for the resident form (two 66 KB workgroups per CU): the compact form
+    if (n_plain > 2 * (size_t)ctx->n_cus) hipLaunchKernelGGL((k_decode<QualModel, true>), dim3((unsigned)n_plain), dim3(64), 0, st, jobs, tq);
+    else hipLaunchKernelGGL((k_decode<QualModel, false>), dim3((unsigned)n_plain), dim3(64), 0, st, jobs, tq);
+    hipLaunchKernelGGL((k_decode<SeqModel, false>), dim3((unsigned)n_plain), dim3(64), 0, st2, jobs, ts);
   }
-  if (n_qual_chunks) hipLaunchKernelGGL(k_decode_chunks<QualModel>, dim3((unsigned)n_qual_chunks), dim3(64), 0, st, jobs, dch, tq);
+  if (n_qual_chunks > 2 * (size_t)ctx->n_cus) hipLaunchKernelGGL((k_decode_chunks<QualModel, true>), dim3((unsigned)n_qual_chunks), dim3(64), 0, st, jobs, dch, tq);
+  else if (n_qual_chunks) hipLaunchKernelGGL((k_decode_chunks<QualModel, false>), dim3((unsigned)n_qual_chunks), dim3(64), 0, st, jobs, dch, tq);
   if (chunks.size() > n_qual_chunks)
-    hipLaunchKernelGGL(k_decode_chunks<SeqModel>, dim3((unsigned)(chunks.size() - n_qual_chunks)), dim3(64), 0, st2, jobs, dch + n_qual_chunks, ts);
+    hipLaunchKernelGGL((k_decode_chunks<SeqModel, false>), dim3((unsigned)(chunks.size() - n_qual_chunks)), dim3(64), 0, st2, jobs, dch + n_qual_chunks, ts);
   FQ_HIP(hipEventRecord(ctx->dec_join, st2));
   FQ_HIP(hipStreamWaitEvent(st, ctx->dec_join, 0));
   fq_timer_span_end(ctx, st);
