@@ -816,6 +816,76 @@ def test_decode_index_parallel_decode(F, mode):
     ctx.close()
 
 
+def test_decode_batches_with_more_chains_than_places(F):
+    """More than two quality chains per CU: the two streams go into separate launches and the quality
+    walk takes its compact form (entries alone in LDS, table offsets by scalar loads).  (a) one block
+    with a decode index every 4096 symbols (mixed read lengths and N's: ~600 strides per stream);
+    (b) 600 small blocks in one batch.  Both restore byte for byte."""
+    raw, recs = _synth(F, 4, 6 << 20, seed=9)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    ctx = F.Context(sft, qft)
+    ctx.set_index_stride(4096)
+    b = ctx.dblock(raw, recs)
+    b.encode(flags=F.F_DECODE_INDEX)
+    ctx.sync()
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    g = b.fetch()
+    for k in ("seq", "qual", "n_count", "n_pos"):
+        assert np.array_equal(g[k], e[k]), k
+    assert (int(recs["len"].sum()) - 1) // 4096 > 520
+    b.wipe()
+    ctx.decode_dblocks([b])
+    ctx.sync()
+    assert b.status()[0] == 0 and np.array_equal(b.fetch_raw(), raw)
+    b.close()
+    # (b) 600 blocks of ~40 records
+    cuts = np.linspace(0, len(recs), 601).astype(int)
+    blocks, originals = [], []
+    for a, z in zip(cuts[:-1], cuts[1:]):
+        lo = 0 if a == 0 else int(recs[a - 1]["qual_off"] + recs[a - 1]["len"] + 1)
+        hi = int(recs[z - 1]["qual_off"] + recs[z - 1]["len"] + 1)
+        braw = raw[lo:hi]
+        brecs = recs[a:z].copy()
+        brecs["seq_off"] -= lo
+        brecs["qual_off"] -= lo
+        db = ctx.dblock(braw, brecs)
+        db.encode()
+        blocks.append(db)
+        originals.append(braw)
+    ctx.sync()
+    for db in blocks:
+        db.wipe()
+    ctx.decode_dblocks(blocks)
+    ctx.sync()
+    for db, braw in zip(blocks, originals):
+        assert db.status()[0] == 0
+        assert np.array_equal(db.fetch_raw(), braw)
+        db.close()
+    ctx.close()
+
+
+def test_page_locked_blocks_are_cached_on_free(F):
+    """fqgpu_host_free keeps page-locked blocks (hipHostFree waits until the device is idle: a farm
+    worker freeing a buffer would wait for every other worker's kernels): the next allocation of the
+    size class gets the block back; small blocks are ordinary heap memory; fqgpu_host_trim empties
+    the cache."""
+    from fqcomp28_amd.binding import lib
+    L = lib()
+    L.fqgpu_host_trim()
+    p = L.fqgpu_host_alloc((3 << 20) - 100)
+    assert p
+    L.fqgpu_host_free(p)
+    q = L.fqgpu_host_alloc((3 << 20) - 4096)   # same class (sizes round up to a multiple of 256 KiB here)
+    assert q == p
+    L.fqgpu_host_free(q)
+    assert L.fqgpu_host_trim() >= 3 << 20
+    assert L.fqgpu_host_trim() == 0
+    small = L.fqgpu_host_alloc(100)
+    assert small
+    L.fqgpu_host_free(small)
+    assert L.fqgpu_host_trim() == 0   # not pinned, not cached
+
+
 # ---------------------------------------------------------------- the C++ drop-in shim
 def test_cpp_workspace_shim_roundtrip(golden_dir):
     """fqcomp28_amd/csrc/workspace.hpp (the reference's Workspace/CompressedBuffers surface over the
