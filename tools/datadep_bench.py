@@ -5,7 +5,9 @@ encode GB/s and decode ns per symbol of 4 x 64 MiB blocks for
                 persist from one position to the next with probability 0.85 (long runs of one
                 context, no reset symbols: what current Illumina output looks like to this model)
   constant   -- every quality 'F', every base 'A' (one context per stream from the fourth symbol on)
-Every run is a round trip (decode output compared byte for byte).  One JSON line per data kind."""
+Every run is a round trip (decode output compared byte for byte).  One JSON line per data kind.
+    python tools/datadep_bench.py [block MiB] [segment of the quality chain kernels, 0 = default]
+(binned data with segments of 4096 / 8192 / 16384: 41.1 / 42.5 / 38.1 GB/s: the segment length is not the lever.)"""
 import json
 import os
 import sys
@@ -47,12 +49,15 @@ def remake(blocks, kind, seed=11):
 
 def main():
     mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    seg = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # segment of the quality chain kernels (0 = default)
     base = bench.make_workload(F, 4 * mib << 20, mib << 20, seed=28)
     for kind in ("synthetic", "binned", "constant"):
         blocks = remake(base, kind)
         sft, qft = bench.sample_tables(F, blocks, 32 << 20, 0)
         ctx = F.Context(sft, qft, device=0)
         ctx.set_lanes(4)
+        if seg:
+            ctx.set_chain_params(seg)
         db = [ctx.dblock(raw, recs) for raw, recs in blocks]
         for b in db:
             b.encode()
@@ -81,7 +86,7 @@ def main():
         ok = all(b.status()[0] == 0 for b in db) and all(np.array_equal(b.fetch_raw(), r) for b, (r, _) in zip(db, blocks))
         raw_bytes = sum(r.size for r, _ in blocks)
         nsym = max(int(r["len"].sum()) for _, r in blocks)
-        print(json.dumps({"data": kind, "blocks": "4 x %d MiB" % mib, "encode_GBps": round(raw_bytes / enc / 1e9, 1),
+        print(json.dumps({"data": kind, "segment": seg, "blocks": "4 x %d MiB" % mib, "encode_GBps": round(raw_bytes / enc / 1e9, 1),
                           "decode_MBps": round(raw_bytes / dec / 1e6, 1), "decode_ns_per_symbol_per_lane": round(dec * 1e9 / nsym, 1),
                           "seq_bytes": int(sum(s["seq_len"] for s in sizes)), "qual_bytes": int(sum(s["qual_len"] for s in sizes)),
                           "roundtrip_ok": bool(ok),
