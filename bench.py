@@ -323,7 +323,9 @@ def main():
                                     "frac": round(d_alg / (d_ms / 1e3) / 1e9 / 8000.0, 7) if d_ms else None,
                                     "launch_ms": round(d_ms, 2), "algorithmic_bytes_per_launch": int(d_alg),
                                     "lanes": 2 * len(dblocks), "ns_per_symbol_per_lane": round(d_ms * 1e6 / max(1, max(int(r["len"].sum()) for _, r in blocks)), 1),
-                                    "traffic": None}
+                                    "traffic": None,
+                                    "limit": "not bytes: the format leaves one serial chain per (block, stream); one wave walks it and is "
+                                             "bound by its own instruction issue, 36 instructions per symbol (DESIGN.md section 5)"}
         # extension: the same blocks coded with a decode index (identical streams + a sidecar of
         # snapshots every --index-stride symbols), decoded with one lane per (stream, stride)
         ctx.set_index_stride(args.index_stride)
