@@ -6,10 +6,12 @@
 //
 // The format gives a decoder nothing to split a stream on: the bit position of a
 // symbol depends on every earlier nbBits and its context on the symbols just decoded
-// (SURVEY.md 7.3).  Parallelism = (blocks in the batch) x 2 streams: one workgroup per
-// (block, stream), one lane walks the chain, the wave only helps where the work is
-// data-parallel (loading the 256 / 8192 initial states, whose bit positions are known
-// from the table logs).  All blocks of a batch are decoded by ONE launch.
+// (SURVEY.md 7.3).  Parallelism = (blocks in the batch) x 2 streams: one 64-lane workgroup per
+// (block, stream) -- or per (block, stream, stride) with the decode index --, the wave walks
+// the chain with everything it decides on in scalar registers and helps where the work is
+// data-parallel (the 256 / 8192 initial entries, whose bit positions are known from the table
+// logs; the bit buffer; the stores).  A batch is one launch, or one per stream when it has
+// more chains than the chip has places (fq_decode_launch).
 #include "fqgpu_internal.h"
 
 #include <vector>
