@@ -90,9 +90,16 @@ namespace {
 struct HostHdr { uint64_t magic, pinned, size, pad[5]; };  // size: bytes of the whole block, header included
 constexpr uint64_t HOST_MAGIC = 0x46514850494E4E44ull;
 constexpr size_t PIN_MIN = 64 << 10;
-std::mutex g_pin_mutex;
-std::multimap<size_t, void *> g_pin_cache;  // block size -> free pinned block
-size_t g_pin_cached = 0;
+struct PinCache {
+  std::mutex mutex;
+  std::multimap<size_t, void *> blocks;  // block size -> free pinned block
+  size_t bytes = 0;
+};
+// (never destroyed: fqgpu_host_free is called from the destructors of the callers' own statics at exit)
+PinCache &pin_cache() {
+  static PinCache *c = new PinCache;
+  return *c;
+}
 size_t pin_class(size_t bytes) {  // rounded up to a multiple of 1/8 of the largest power of two below it
   size_t step = 1;
   while ((step << 4) <= bytes) step <<= 1;
@@ -113,9 +120,10 @@ extern "C" void *fqgpu_host_alloc(size_t bytes) {
   if (total >= PIN_MIN) {
     total = pin_class(total);
     {
-      std::lock_guard<std::mutex> lock(g_pin_mutex);
-      auto it = g_pin_cache.find(total);
-      if (it != g_pin_cache.end()) { p = it->second; g_pin_cache.erase(it); g_pin_cached -= total; pinned = true; }
+      PinCache &pc = pin_cache();
+      std::lock_guard<std::mutex> lock(pc.mutex);
+      auto it = pc.blocks.find(total);
+      if (it != pc.blocks.end()) { p = it->second; pc.blocks.erase(it); pc.bytes -= total; pinned = true; }
     }
     if (!p) {
       int n = 0;
@@ -143,10 +151,11 @@ extern "C" void fqgpu_host_free(void *p) {
   if (!h->pinned) { free(h); return; }
   const size_t total = h->size;
   {
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    if (g_pin_cached + total <= pin_cache_limit()) {
-      g_pin_cache.emplace(total, h);
-      g_pin_cached += total;
+    PinCache &pc = pin_cache();
+    std::lock_guard<std::mutex> lock(pc.mutex);
+    if (pc.bytes + total <= pin_cache_limit()) {
+      pc.blocks.emplace(total, h);
+      pc.bytes += total;
       return;
     }
   }
@@ -157,10 +166,11 @@ extern "C" size_t fqgpu_host_trim(void) {
   std::multimap<size_t, void *> drop;
   size_t bytes;
   {
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    drop.swap(g_pin_cache);
-    bytes = g_pin_cached;
-    g_pin_cached = 0;
+    PinCache &pc = pin_cache();
+    std::lock_guard<std::mutex> lock(pc.mutex);
+    drop.swap(pc.blocks);
+    bytes = pc.bytes;
+    pc.bytes = 0;
   }
   for (auto &kv : drop) (void)hipHostFree(kv.second);
   return bytes;
