@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --skip-cpu --skip-decode --skip-host"
-rm -rf $O/r02_prof4 $O/r02_prof1 $O/r02_pmc_f $O/r02_pmc_w $O/r02_pmc_sq
+rm -rf $O/r02_prof4 $O/r02_prof1 $O/r02_pmc_f $O/r02_pmc_w $O/r02_pmc_sq $O/r02_pmc_insts
 # 1. per-kernel time of the timed encode region, default lanes (4 blocks in flight)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_prof4 -o p4 -- $B > $O/r02_prof4.log 2>&1 && echo "prof4 ok" &&
 # 2. the same with one block in flight
@@ -17,5 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_prof1 -o p1 -- $B
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/r02_pmc_f -o f -- $B --steps 1 --warmup 1 > $O/r02_pmc_f.log 2>&1 && echo "pmc_f ok" &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/r02_pmc_w -o w -- $B --steps 1 --warmup 1 > $O/r02_pmc_w.log 2>&1 && echo "pmc_w ok" &&
 # 5. wave-cycle breakdown, one block in flight
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/r02_pmc_sq -o sq -- $B --steps 1 --warmup 1 --lanes 1 > $O/r02_pmc_sq.log 2>&1 && echo "pmc_sq ok"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/r02_pmc_sq -o sq -- $B --steps 1 --warmup 1 --lanes 1 > $O/r02_pmc_sq.log 2>&1 && echo "pmc_sq ok" &&
+# 6. wave-instructions by class, one block in flight
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES --kernel-trace --output-format csv -d $O/r02_pmc_insts -o insts -- $B --steps 1 --warmup 1 --lanes 1 > $O/r02_pmc_insts.log 2>&1 && echo "pmc_insts ok"
 ls $O/r02_prof4 $O/r02_pmc_f | head -20

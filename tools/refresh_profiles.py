@@ -118,6 +118,23 @@ if sq:
                     100 * c["SQ_WAIT_INST_LDS"] / wc, 100 * c["SQ_ACTIVE_INST_ANY"] / wc, c["SQ_LDS_IDX_ACTIVE"],
                     100 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), c["SQ_BUSY_CYCLES"]))
 
+ins = sorted(glob.glob(R + "gpurun_out/r02_pmc_insts/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+if ins:
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.Counter()
+    for r in csv.DictReader(open(ins[-1])):
+        n = short(r["Kernel_Name"])
+        acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_WAVES":
+            calls[n] += 1
+    cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_WAVES"]
+    with open(R + "profiles/%s_pmc_instructions_per_launch.csv" % TAG, "w") as f:
+        f.write("kernel,launches,wave_insts_VALU,SALU,LDS,VMEM_RD,VMEM_WR,SMEM,waves\n")
+        for n, c in sorted(acc.items(), key=lambda kv: -sum(kv[1][k] for k in cols[:6]) / max(calls[kv[0]], 1)):
+            if n.startswith(skip):
+                continue
+            f.write("\"%s\",%d,%s\n" % (n, calls[n], ",".join("%.4g" % (c[k] / max(calls[n], 1)) for k in cols)))
+
 d = last_json(R + "gpurun_out/r2_bench_default.log")
 json.dump(d, open(R + "profiles/%s_bench_default_line.json" % TAG, "w"), indent=1)
 e = last_json(R + "gpurun_out/r02_prof4.log")
