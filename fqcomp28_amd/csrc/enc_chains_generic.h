@@ -18,14 +18,24 @@
 // Every lane walks at most S symbols, whatever the data: a context without reset symbols (binned
 // or constant qualities) costs state-set work instead of one endless serial chain.
 constexpr unsigned SEG_NONE = 0xFFFFFFFFu;
+// class of a segment (SegArrays::cls): 0 = opaque, 1 .. 64 = anchored (the state behind its anchor
+// symbol is one of that many candidates; 1 = reset symbol: transparent), 0xFF = uniform (S times
+// one symbol whose count is too large to be an anchor)
+constexpr unsigned SEG_CLS_OPAQUE = 0, SEG_CLS_UNIFORM = 0xFF, SEG_MAX_CAND = 64;
+constexpr unsigned SEG_SLOT = 16;  // lanes of one candidate walk: four walks share a wave
 
 // segment table of one stream (all arrays indexed by the global segment number)
 struct SegArrays {
-  uint32_t *first_reset;  // offset of the first reset symbol inside the segment, or SEG_NONE
-  uint32_t *fidx;         // function slot of an opaque segment
-  uint32_t *olist;        // opaque segments that have a successor, in no particular order
-  uint32_t *n_opaque;     // length of olist
+  uint32_t *anchor;       // offset of the anchor symbol inside the segment (cls 1 .. 64), the symbol (uniform), or SEG_NONE
+  uint32_t *fidx;         // function slot of a segment whose successor needs one, or SEG_NONE
+  uint32_t *olist;        // segments that get a full function from k_seg_setfunc, in no particular order
+  uint32_t *tlist;        // candidate walks behind an anchor: segment * 4 + quarter (16 candidates each)
+  uint32_t *hlist;        // candidate walks up to an anchor: segment * 4 + quarter of the predecessor's candidates
+  uint32_t *counts;       // lengths of olist, tlist, hlist
+  uint32_t *usym;         // [B] the symbol whose power table the context owns in this block, or SEG_NONE
   uint16_t *entry_state;  // state in front of the first symbol of every segment
+  uint16_t *cand_exit;    // [segment][64] state at the end of the segment for every candidate of its anchor
+  uint8_t *cls;           // class of every segment
 };
 
 template <class M>
@@ -38,53 +48,160 @@ __device__ __forceinline__ unsigned seg_ctx_of(const uint32_t *__restrict__ base
   return lo;
 }
 
+// One wave per segment.  First reset symbol (stops there: class 1); otherwise the first occurrence
+// of the symbol with the fewest table cells if that is <= 64 (class = that number: after this
+// symbol the state is one of so many known candidates); otherwise uniform or opaque.
 template <class M>
 __global__ void __launch_bounds__(256)
 k_seg_scan(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
-           const unsigned long long *__restrict__ reset_mask, const uint32_t *__restrict__ logs, unsigned S,
-           SegArrays sa) {
-  constexpr unsigned B = M::B;
+           const unsigned long long *__restrict__ reset_mask, const int16_t *__restrict__ norm,
+           const uint32_t *__restrict__ logs, unsigned S, SegArrays sa) {
+  constexpr unsigned B = M::B, A = M::A;
+  __shared__ uint8_t s_cells[4][64];
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
-  const unsigned seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned wave = threadIdx.x >> 6, seg = blockIdx.x * 4 + wave;
   if (seg >= seg_base[B]) return;  // the grid is an upper bound
   const unsigned lane = fq_lane();
   const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
   const unsigned n = ctx_count[c], begin = k * S, end = min(n, begin + S);
   const unsigned long long mask = reset_mask[c];
   const uint8_t *sym = sorted_sym + ctx_start[c];
-  unsigned found = SEG_NONE;
-  if (mask != 0ull) {
-    for (unsigned b0 = begin; b0 < end; b0 += 1024) {
-      const unsigned p = b0 + 16 * lane;
-      unsigned hit = 16;
-      if (p < end) {  // the run is padded to 16 bytes: whole-group loads stay inside it
-        const uint4 v = *reinterpret_cast<const uint4 *>(sym + p);
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  {  // table cells of every symbol (255: too many for an anchor, or none)
+    const int v = lane < A ? (int)norm[(size_t)c * A + lane] : 0;
+    s_cells[wave][lane] = (uint8_t)(v == -1 ? 1 : (v >= 1 && v <= (int)SEG_MAX_CAND) ? v : 255);
+    fq_lds_wave_sync();
+  }
+  const uint8_t *cells = s_cells[wave];
+  unsigned found = SEG_NONE;             // first reset symbol
+  unsigned best = (255u << 20) | 0xFFFFFu;  // cells << 20 | offset of the best anchor so far
+  bool uniform = end - begin == S;       // (a short last segment needs no function)
+  unsigned s0 = 0;
+  for (unsigned b0 = begin; b0 < end; b0 += 1024) {
+    const unsigned p = b0 + 16 * lane;
+    unsigned hit = 16, mine = 0xFFFFFFFFu;
+    bool same = true;
+    if (p < end) {  // the run is padded to 16 bytes: whole-group loads stay inside it
+      const uint4 v = *reinterpret_cast<const uint4 *>(sym + p);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+      if (b0 == begin) s0 = (unsigned)__builtin_amdgcn_readfirstlane(v.x) & (A - 1);
 #pragma unroll
-        for (int j = 15; j >= 0; j--) {
-          const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & (unsigned)(M::A - 1);
-          if (p + j < end && ((mask >> s) & 1ull)) hit = (unsigned)j;
+      for (int j = 15; j >= 0; j--) {
+        const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & (A - 1);
+        if (p + j < end) {
+          if ((mask >> s) & 1ull) hit = (unsigned)j;
+          const unsigned off = b0 - begin + 16 * lane + (unsigned)j;  // (anchors are looked for in the first 2^20 symbols)
+          if (off < (1u << 20)) mine = min(mine, ((unsigned)cells[s] << 20) | off);
+          same = same && s == s0;
         }
       }
-      const unsigned long long any = __ballot(hit < 16);
-      if (any) {
-        const unsigned l0 = (unsigned)__ffsll((long long)any) - 1u;
-        found = (b0 - begin) + 16 * l0 + (unsigned)__shfl((int)hit, (int)l0);
-        break;
-      }
     }
+    const unsigned long long any = __ballot(hit < 16);
+    if (any) {
+      const unsigned l0 = (unsigned)__ffsll((long long)any) - 1u;
+      found = (b0 - begin) + 16 * l0 + (unsigned)__shfl((int)hit, (int)l0);
+      break;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine = min(mine, (unsigned)__shfl_xor((int)mine, d));
+    best = min(best, mine);
+    uniform = uniform && __ballot(!same) == 0ull;
   }
   if (lane == 0) {
-    sa.first_reset[seg] = found;
-    if (k == 0) sa.entry_state[seg] = (uint16_t)(1u << logs[c]);  // FSE_initCState
-    const unsigned nseg = seg_base[c + 1] - seg_base[c];
-    unsigned slot = SEG_NONE;
-    if (found == SEG_NONE && k + 1 < nseg) {
-      slot = atomicAdd(sa.n_opaque, 1u);
-      sa.olist[slot] = seg | (k == 0 ? 0x80000000u : 0u);
+    unsigned cls = SEG_CLS_OPAQUE, anchor = SEG_NONE;
+    if (found != SEG_NONE) { cls = 1; anchor = found; }
+    else if ((best >> 20) <= SEG_MAX_CAND) { cls = best >> 20; anchor = best & 0xFFFFFu; }
+    else if (uniform) {  // one power table per context and block: the first symbol to ask gets it
+      const unsigned old = atomicCAS(&sa.usym[c], SEG_NONE, s0);
+      if (old == SEG_NONE || old == s0) { cls = SEG_CLS_UNIFORM; anchor = s0; }
     }
-    sa.fidx[seg] = slot;
+    sa.cls[seg] = (uint8_t)cls;
+    sa.anchor[seg] = anchor;
+    if (k == 0) sa.entry_state[seg] = (uint16_t)(1u << logs[c]);  // FSE_initCState
   }
+}
+
+// One thread per segment: who computes the function of a segment whose successor needs one.
+//   opaque                          -> k_seg_setfunc (olist), slot = the segment
+//   uniform                         -> the context's power table (slot pbase + context)
+//   anchored, 2 .. 64 candidates    -> k_seg_tails walks every candidate to the end of the segment;
+//       k_seg_heads walks every state the segment can be entered with up to the anchor -- possible
+//       when the predecessor is anchored too (its candidates' exits) or the chain starts here;
+//       behind an opaque or uniform segment the entry state can be anything: k_seg_setfunc
+//   reset symbol (1 candidate)      -> nothing: k_seg_walk<1> knows the exit state
+template <class M>
+__global__ void __launch_bounds__(256)
+k_seg_plan(const uint32_t *__restrict__ arrays, unsigned pbase, SegArrays sa) {
+  constexpr unsigned B = M::B;
+  const uint32_t *seg_base = arrays + B + (B + 1);
+  const unsigned seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= seg_base[B]) return;
+  const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
+  const unsigned nseg = seg_base[c + 1] - seg_base[c];
+  const unsigned cls = sa.cls[seg];
+  unsigned slot = SEG_NONE;
+  if (k + 1 < nseg && cls != 1) {
+    bool full = cls == SEG_CLS_OPAQUE;
+    if (cls == SEG_CLS_UNIFORM) {
+      slot = pbase + c;
+    } else {
+      slot = seg;
+      if (!full) {
+        const unsigned nq = (cls + SEG_SLOT - 1) / SEG_SLOT;
+        const unsigned t0 = atomicAdd(&sa.counts[1], nq);
+        for (unsigned q = 0; q < nq; q++) sa.tlist[t0 + q] = seg * 4 + q;
+        const unsigned pred = k ? (unsigned)sa.cls[seg - 1] : 1u;
+        if (pred == SEG_CLS_OPAQUE || pred == SEG_CLS_UNIFORM) {
+          full = true;
+        } else {
+          const unsigned nh = (pred + SEG_SLOT - 1) / SEG_SLOT;
+          const unsigned h0 = atomicAdd(&sa.counts[2], nh);
+          for (unsigned q = 0; q < nh; q++) sa.hlist[h0 + q] = seg * 4 + q;
+        }
+      }
+      if (full) sa.olist[atomicAdd(&sa.counts[0], 1u)] = seg;
+    }
+  }
+  sa.fidx[seg] = slot;
+}
+
+// T_s^S for the context's uniform symbol s: the function of a segment that is S times s, by
+// square and multiply over the bits of S.  Slot pbase + context of the function buffer.
+template <class M>
+__global__ void __launch_bounds__(256)
+k_seg_pow(const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, unsigned S, unsigned pbase,
+          unsigned fstride, SegArrays sa, uint16_t *__restrict__ fbuf) {
+  __shared__ uint16_t base[1 << 12], acc[1 << 12], tmp[1 << 12];
+  const unsigned c = blockIdx.x;
+  const unsigned s = sa.usym[c];
+  if (s == SEG_NONE) return;  // (uniform)
+  const uint32_t *tbl = ct + ct_off[c];
+  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
+  const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
+  const uint32_t *tt = tbl + 1 + (size >> 1);
+  const int dfs = (int)tt[2 * s];
+  const unsigned dnb = tt[2 * s + 1];
+  for (unsigned i = threadIdx.x; i < size; i += blockDim.x) {
+    const unsigned x = size + i, nb = (x + dnb) >> 16;
+    base[i] = (uint16_t)(st[(int)(x >> nb) + dfs] - size);
+    acc[i] = (uint16_t)i;
+  }
+  __syncthreads();
+  for (unsigned e = S; e; e >>= 1) {
+    if (e & 1u) {
+      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) tmp[i] = base[acc[i]];
+      __syncthreads();
+      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) acc[i] = tmp[i];
+      __syncthreads();
+    }
+    if (e > 1u) {
+      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) tmp[i] = base[base[i]];
+      __syncthreads();
+      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) base[i] = tmp[i];
+      __syncthreads();
+    }
+  }
+  uint16_t *f = fbuf + (size_t)(pbase + c) * fstride;
+  for (unsigned i = threadIdx.x; i < size; i += blockDim.x) f[i] = (uint16_t)(size + acc[i]);
 }
 
 // symbols [i, end) of a context's run walked from state x: packed (nb, bits) into out, 16
@@ -124,7 +241,7 @@ __device__ __forceinline__ unsigned seg_walk_range(const LdsCTable &t, const uin
 
 // PASS 1: lane = transparent segment, from behind its first reset symbol to its end.
 // PASS 2: lane = segment, its head up to and including the first reset symbol (transparent) or
-//         all of it (opaque), from the resolved entry state.
+//         all of it (every other class), from the resolved entry state.
 template <class M, int PASS>
 __global__ void __launch_bounds__(64)
 k_seg_walk(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
@@ -147,20 +264,116 @@ k_seg_walk(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
   const uint8_t *sym = sorted_sym + ctx_start[c];
   uint16_t *out = out16 + ctx_start[c];
   const unsigned begin = k * S, end = min(n, begin + S);
-  const unsigned fr = sa.first_reset[seg];
+  const bool reset = sa.cls[seg] == 1;  // transparent: the segment holds a reset symbol
+  const unsigned fr = sa.anchor[seg];
   unsigned x, i0, i1;
   if (PASS == 1) {
-    if (fr == SEG_NONE) return;
+    if (!reset) return;
     i0 = begin + fr + 1; i1 = end;
     x = reset_state(t, sym[begin + fr] & (unsigned)(M::A - 1));
   } else {
-    i0 = begin; i1 = fr == SEG_NONE ? end : begin + fr + 1;
+    i0 = begin; i1 = reset ? begin + fr + 1 : end;
     x = sa.entry_state[seg];
   }
   x = seg_walk_range<M>(t, sym, out, i0, i1, x);
   if (PASS == 1 && k + 1 < nseg) sa.entry_state[seg + 1] = (uint16_t)x;
-  if (k == nseg - 1 && (PASS == 1 || fr == SEG_NONE)) final_state[c] = (uint16_t)x;
+  if (k == nseg - 1 && (PASS == 1 || !reset)) final_state[c] = (uint16_t)x;
   if (PASS == 2 && fq_lane() == 0) atomicMax(&res->refixed, min(S, n));
+}
+
+// ---- anchored segments without a reset symbol: candidate walks ------------------------------
+// A symbol with n table cells leaves the coder in one of n states whatever it was in: cell j of the
+// symbol, j = (x >> nb) - n (zstd fse.h: FSE_encodeSymbol lands on stateTable[(x >> nb) +
+// deltaFindState], deltaFindState = first cell - n).  n = 1 is the reset symbol above; for
+// n <= 64 one lane per candidate walks on from the anchor:
+//   k_seg_tails  to the end of the segment: cand_exit[segment][j]
+//   k_seg_heads  from every state the segment can be ENTERED with -- the predecessor's cand_exit,
+//                or the one known entry state behind a reset symbol / at the start of the chain --
+//                up to the anchor: which candidate that is, hence F[entry state] = cand_exit[that]
+// F has 2^log entries like a function of k_seg_setfunc, but only the (at most 64) entries that can
+// occur are written; k_seg_compose / k_seg_resolve2/3 treat it like any other function.  Sixteen
+// lanes per walk and four walks per wave, each with its own context's CTable in LDS: a block of
+// binned qualities costs n / 64 of a gather per symbol instead of the 1 .. 32 of the state sets.
+__device__ __forceinline__ LdsCTable slot_ctable(uint32_t *mine, const uint32_t *__restrict__ tbl, unsigned j, unsigned A) {
+  const unsigned log = tbl[0] & 0xFFFFu;
+  const unsigned words = 1u + (1u << (log - 1)) + 2u * A;
+  for (unsigned i = j; i < words; i += SEG_SLOT) mine[i] = tbl[i];
+  LdsCTable t;
+  t.log = log;
+  t.state_table = reinterpret_cast<const uint16_t *>(mine) + 2;
+  t.tt = mine + 1 + (1u << (log - 1));
+  return t;
+}
+
+// symbols [i, end) of a run walked from state x, nothing written; returns the final state
+template <class M>
+__device__ __forceinline__ unsigned seg_state_range(const LdsCTable &t, const uint8_t *__restrict__ sym, unsigned i,
+                                                    unsigned end, unsigned x) {
+  auto step = [&](unsigned s) {
+    const int dfs = (int)t.tt[2 * s];
+    const unsigned nb = (x + t.tt[2 * s + 1]) >> 16;
+    x = t.state_table[(int)(x >> nb) + dfs];
+  };
+  while (i < end && (i & 15u)) { step(sym[i] & (unsigned)(M::A - 1)); i++; }
+  if (i + 16 <= end) {
+    const uint4 *sym16 = reinterpret_cast<const uint4 *>(sym);
+    uint4 cur = sym16[i >> 4];
+    while (i + 16 <= end) {
+      const uint4 nxt = i + 32 <= end ? sym16[(i >> 4) + 1] : cur;
+      const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+      for (int j = 0; j < 16; j++) step((w[j >> 2] >> (8 * (j & 3))) & (unsigned)(M::A - 1));
+      i += 16;
+      cur = nxt;
+    }
+  }
+  while (i < end) { step(sym[i] & (unsigned)(M::A - 1)); i++; }
+  return x;
+}
+
+template <class M, bool HEADS>
+__global__ void __launch_bounds__(64)
+k_seg_cand(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
+           const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, unsigned S, unsigned slot_words,
+           unsigned fstride, SegArrays sa, uint16_t *__restrict__ fbuf) {
+  extern __shared__ uint32_t lds[];
+  constexpr unsigned B = M::B;
+  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
+  const unsigned n_entries = HEADS ? sa.counts[2] : sa.counts[1];
+  const uint32_t *list = HEADS ? sa.hlist : sa.tlist;
+  const unsigned lane = fq_lane(), slot = lane / SEG_SLOT, j = lane % SEG_SLOT;
+  uint32_t *mine = lds + slot * slot_words;
+  for (unsigned w = blockIdx.x; w * (64 / SEG_SLOT) < n_entries; w += gridDim.x) {
+    const unsigned ei = w * (64 / SEG_SLOT) + slot;
+    fq_lds_wave_sync();  // the previous round's tables are no longer read
+    if (ei >= n_entries) continue;  // (whole slots; the loop bound is uniform)
+    const unsigned e = list[ei], seg = e >> 2, q = e & 3u;
+    const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
+    const LdsCTable t = slot_ctable(mine, ct + ct_off[c], j, M::A);
+    fq_lds_wave_sync();
+    const unsigned size = 1u << t.log;
+    const unsigned n = ctx_count[c], begin = k * S, end = min(n, begin + S);
+    const uint8_t *sym = sorted_sym + ctx_start[c];
+    const unsigned r = begin + sa.anchor[seg], cells = sa.cls[seg];
+    const unsigned s = sym[r] & (unsigned)(M::A - 1);
+    const int dfs = (int)t.tt[2 * s];
+    if (!HEADS) {
+      const unsigned cand = q * SEG_SLOT + j;
+      if (cand >= cells) continue;
+      unsigned x = t.state_table[dfs + (int)cells + (int)cand];
+      x = seg_state_range<M>(t, sym, r + 1, end, x);
+      sa.cand_exit[(size_t)seg * SEG_MAX_CAND + cand] = (uint16_t)x;
+    } else {
+      const unsigned pred = k ? (unsigned)sa.cls[seg - 1] : 1u;
+      const unsigned cand = q * SEG_SLOT + j;
+      if (cand >= pred) continue;
+      const unsigned entry = pred == 1 ? (unsigned)sa.entry_state[seg] : (unsigned)sa.cand_exit[(size_t)(seg - 1) * SEG_MAX_CAND + cand];
+      const unsigned x = seg_state_range<M>(t, sym, begin, r, entry);
+      const unsigned nb = (x + t.tt[2 * s + 1]) >> 16;
+      const unsigned u = (x >> nb) - cells;  // which cell of the anchor symbol
+      fbuf[(size_t)seg * fstride + (entry - size)] = sa.cand_exit[(size_t)seg * SEG_MAX_CAND + u];
+    }
+  }
 }
 
 // n classes (states in L.list) stepped through words [w0, w1) of the segment with the CTable
@@ -210,9 +423,9 @@ k_seg_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
   extern __shared__ uint32_t lds[];
   __shared__ SetsWaveLds L;
   constexpr unsigned B = M::B;
-  if (blockIdx.x >= *sa.n_opaque) return;  // the grid is an upper bound
+  if (blockIdx.x >= sa.counts[0]) return;  // the grid is an upper bound
   const uint32_t *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
-  const unsigned seg = sa.olist[blockIdx.x] & 0x7FFFFFFFu;
+  const unsigned seg = sa.olist[blockIdx.x];
   const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
   const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
   const unsigned log = t.log, size = 1u << log, lane = fq_lane();
@@ -284,7 +497,7 @@ k_seg_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
     }
     cur = nxt;
   }
-  uint16_t *f = fbuf + (size_t)blockIdx.x * fstride;  // F[entry - size] = exit
+  uint16_t *f = fbuf + (size_t)seg * fstride;  // F[entry - size] = exit
 #pragma unroll
   for (unsigned j = 0; j < PER0; j++) {
     const unsigned xi = lane + 64u * j;
@@ -338,10 +551,12 @@ k_seg_compose(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ 
 #pragma unroll
       for (unsigned j = 0; j < PER0; j++) x[j] = e;
     } else {
+      // (a function of k_seg_cand is defined on the states that can occur only: whatever else
+      // sits in its slot is brought into range and never followed by the resolve kernels)
       const uint16_t *f = fbuf + (size_t)sl * fstride;
 #pragma unroll
       for (unsigned j = 0; j < PER0; j++)
-        if (j < per) x[j] = f[x[j] - size];
+        if (j < per) x[j] = size | ((unsigned)f[x[j] - size] & (size - 1));
     }
   }
   uint16_t *g = ia.g + (size_t)item * fstride;

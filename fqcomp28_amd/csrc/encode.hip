@@ -167,9 +167,18 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   // generic chain kernels (quality stream; sequence stream with FQGPU_CHAIN_SEQ_GENERIC)
   const unsigned gen_max_segs = n_sym / S + B + 1;
   const unsigned gen_fstride = 1u << tab.max_log;
+  // segment tables of the generic chain kernels (SegArrays, then ItemArrays), every array 16-byte aligned
+  auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t gs = gen_max_segs;
+  const size_t sa_anchor = 0, sa_fidx = al16(sa_anchor + gs * 4), sa_olist = al16(sa_fidx + gs * 4), sa_tlist = al16(sa_olist + gs * 4),
+               sa_hlist = al16(sa_tlist + gs * 16), sa_counts = al16(sa_hlist + gs * 16), sa_usym = sa_counts + 16,
+               sa_entry = al16(sa_usym + (size_t)B * 4), sa_cand = al16(sa_entry + gs * 2), sa_cls = al16(sa_cand + gs * SEG_MAX_CAND * 2),
+               ia_has_g = al16(sa_cls + gs), ia_entry = al16(ia_has_g + (size_t)max_items * 4), ia_g = al16(ia_entry + (size_t)max_items * 2),
+               seg_arrays_bytes = ia_g + (size_t)max_items * gen_fstride * 2 + 64;
+  const unsigned gen_pbase = gen_max_segs;  // function slots: one per segment, then one power table per context
   if (!serial_seq) {
-    if ((rc = sc.seg_arrays.reserve((size_t)gen_max_segs * 16 + 64 + (size_t)max_items * (2 * gen_fstride + 8) + 64))) return rc;
-    if ((rc = sc.seq_fbuf.reserve(((size_t)n_sym / S + 2) * gen_fstride * 2 + 64))) return rc;
+    if ((rc = sc.seg_arrays.reserve(seg_arrays_bytes))) return rc;
+    if ((rc = sc.seq_fbuf.reserve(((size_t)gen_max_segs + B) * gen_fstride * 2 + 64))) return rc;
   }
   if (serial_seq) {
     if ((rc = sc.seq_plan.reserve((size_t)SEGPLAN_WORDS * 4 + (size_t)seq_max_segs * 2 + 64))) return rc;
@@ -278,22 +287,32 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                          entry, final_state, res);
     }
   } else {
+    uint8_t *sab = sc.seg_arrays.as<uint8_t>();
     SegArrays sa;
-    sa.first_reset = sc.seg_arrays.as<uint32_t>();
-    sa.fidx = sa.first_reset + gen_max_segs;
-    sa.olist = sa.fidx + gen_max_segs;
-    sa.n_opaque = sa.olist + gen_max_segs;
-    sa.entry_state = reinterpret_cast<uint16_t *>(sa.n_opaque + 4);
+    sa.anchor = reinterpret_cast<uint32_t *>(sab + sa_anchor);
+    sa.fidx = reinterpret_cast<uint32_t *>(sab + sa_fidx);
+    sa.olist = reinterpret_cast<uint32_t *>(sab + sa_olist);
+    sa.tlist = reinterpret_cast<uint32_t *>(sab + sa_tlist);
+    sa.hlist = reinterpret_cast<uint32_t *>(sab + sa_hlist);
+    sa.counts = reinterpret_cast<uint32_t *>(sab + sa_counts);
+    sa.usym = reinterpret_cast<uint32_t *>(sab + sa_usym);
+    sa.entry_state = reinterpret_cast<uint16_t *>(sab + sa_entry);
+    sa.cand_exit = reinterpret_cast<uint16_t *>(sab + sa_cand);
+    sa.cls = sab + sa_cls;
     uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
-    FQ_HIP(hipMemsetAsync(sa.n_opaque, 0, 4, st));
+    const unsigned cand_lds = (64 / SEG_SLOT) * lds_ct, cand_grid = min(gen_max_segs / (64 / SEG_SLOT) + 1, 8u * ctx->n_cus);
+    FQ_HIP(hipMemsetAsync(sa.counts, 0, 16, st));
+    FQ_HIP(hipMemsetAsync(sa.usym, 0xFF, (size_t)B * 4, st));
     if (!dbg_off) hipLaunchKernelGGL(k_seg_scan<M>, dim3((gen_max_segs + 3) / 4), dim3(256), 0, st, sc.sorted_sym.as<uint8_t>(),
-                       arrays, tab.reset_mask, tab.logs, S, sa);
+                       arrays, tab.reset_mask, tab.norm, tab.logs, S, sa);
+    if (!dbg_off) hipLaunchKernelGGL(k_seg_plan<M>, dim3((gen_max_segs + 255) / 256), dim3(256), 0, st, arrays, gen_pbase, sa);
     FQ_SPAN_END();
     FQ_SPAN_BEGIN(M::STREAM ? "qual.walk1" : "seq.walk1");  dbg_off = (dbg_mask & 8u) != 0;
     if (!dbg_off) hipLaunchKernelGGL((k_seg_walk<M, 1>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                        sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, sa, res);
     FQ_SPAN_END();
     FQ_SPAN_BEGIN(M::STREAM ? "qual.setfunc" : "seq.setfunc");  dbg_off = (dbg_mask & 8u) != 0;
+    if (!dbg_off) hipLaunchKernelGGL(k_seg_pow<M>, dim3(B), dim3(256), 0, st, tab.ct, tab.ct_off, S, gen_pbase, gen_fstride, sa, fbuf);
     if (dbg_off) {
     } else if (tab.max_log <= 11)
       hipLaunchKernelGGL((k_seg_setfunc<M, 32>), dim3(n_sym / S + 1), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
@@ -302,12 +321,20 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
       hipLaunchKernelGGL((k_seg_setfunc<M, 64>), dim3(n_sym / S + 1), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                          arrays, tab.ct, tab.ct_off, S, gen_fstride, sa, fbuf);
     FQ_SPAN_END();
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.cand" : "seq.cand");  dbg_off = (dbg_mask & 8u) != 0;
+    if (!dbg_off) {
+      hipLaunchKernelGGL((k_seg_cand<M, false>), dim3(cand_grid), dim3(64), cand_lds, st, sc.sorted_sym.as<uint8_t>(), arrays, tab.ct,
+                         tab.ct_off, S, lds_ct / 4, gen_fstride, sa, fbuf);
+      hipLaunchKernelGGL((k_seg_cand<M, true>), dim3(cand_grid), dim3(64), cand_lds, st, sc.sorted_sym.as<uint8_t>(), arrays, tab.ct,
+                         tab.ct_off, S, lds_ct / 4, gen_fstride, sa, fbuf);
+    }
+    FQ_SPAN_END();
     FQ_SPAN_BEGIN(M::STREAM ? "qual.resolve" : "seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
     if (!dbg_off) {
       ItemArrays ia;
-      ia.has_g = reinterpret_cast<uint32_t *>(sc.seg_arrays.as<uint8_t>() + (((size_t)gen_max_segs * 16 + 64 + 15) & ~(size_t)15));
-      ia.item_entry = reinterpret_cast<uint16_t *>(ia.has_g + max_items);
-      ia.g = ia.item_entry + ((max_items + 7) & ~7u);
+      ia.has_g = reinterpret_cast<uint32_t *>(sab + ia_has_g);
+      ia.item_entry = reinterpret_cast<uint16_t *>(sab + ia_entry);
+      ia.g = reinterpret_cast<uint16_t *>(sab + ia_g);
       if (tab.max_log <= 11)
         hipLaunchKernelGGL((k_seg_compose<M, 32>), dim3(max_items), dim3(64), 0, st, arrays, tab.logs, fbuf, gen_fstride, sa, ia);
       else
@@ -373,7 +400,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     if (n_snap) {
       const uint32_t *seg_prefix = serial_seq ? sc.seq_plan.as<uint32_t>() + 2 * (B + 1) : arrays + B + (B + 1);
       const uint16_t *entry = serial_seq ? reinterpret_cast<const uint16_t *>(sc.seq_plan.as<uint32_t>() + SEGPLAN_WORDS)
-                                         : reinterpret_cast<const uint16_t *>(sc.seg_arrays.as<uint32_t>() + 3 * (size_t)gen_max_segs + 4);
+                                         : reinterpret_cast<const uint16_t *>(sc.seg_arrays.as<uint8_t>() + sa_entry);
       hipLaunchKernelGGL(k_index_states<M>, dim3(B, (n_snap + 63) / 64), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                          arrays, sc.tile_base.as<uint32_t>(), T, n_sym, stride, seg_prefix, entry, serial_seq ? 1 : 0,
                          serial_seq ? seq_S : S, tab.ct, tab.ct_off, final_state, b->index[M::STREAM]);

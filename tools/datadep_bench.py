@@ -53,7 +53,7 @@ def main():
     base = bench.make_workload(F, 4 * mib << 20, mib << 20, seed=28)
     for kind in ("synthetic", "binned", "constant"):
         blocks = remake(base, kind)
-        sft, qft = bench.sample_tables(F, blocks, 32 << 20, 0)
+        sft, qft = bench.sample_tables(F, blocks, max(32, mib // 2) << 20, 0)
         ctx = F.Context(sft, qft, device=0)
         ctx.set_lanes(4)
         if seg:
