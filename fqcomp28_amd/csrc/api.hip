@@ -295,7 +295,7 @@ static void free_lane(EncLane &l) {
   for (int s = 0; s < 2; s++) {
     EncScratch &e = l.enc[s];
     DevBuf *eb[] = {&e.slot_of, &e.keys, &e.sorted_sym, &e.out16, &e.tile_hist, &e.tile_base, &e.group_sum,
-                    &e.ctx_arrays, &e.seg_state, &e.seg_arrays, &e.seq_bdesc, &e.seq_plan, &e.seq_fbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp, &e.tile_runs, &e.tile_sync, &e.dbg_enc16};
+                    &e.ctx_arrays, &e.seg_state, &e.seg_arrays, &e.seq_bdesc, &e.seq_plan, &e.seq_fbuf, &e.seq_cbuf, &e.tile_bits, &e.tile_bit_base, &e.scan_tmp, &e.tile_runs, &e.tile_sync, &e.dbg_enc16};
     for (DevBuf *b : eb) b->release();
   }
   hipEvent_t evs[] = {l.ev_fork, l.ev_join};
@@ -414,7 +414,8 @@ extern "C" int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len,
 
 // ------------------------------------------------------------------ handle
 static void free_tables(DevTables &t) {
-  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off, t.next1, t.next2, t.reset_mask};
+  void *ps[] = {t.norm, t.logs, t.log_prefix, t.ct, t.ct_off, t.dt, t.dt_off, t.next1, t.next2, t.reset_mask,
+                t.seq_pow[0], t.seq_pow[1], t.seq_pow[2], t.seq_pow[3]};
   for (void *p : ps) if (p) (void)hipFree(p);
   t = DevTables();
 }
@@ -528,6 +529,14 @@ extern "C" int fqgpu_ctx_set_seq_group(fqgpu_ctx *ctx, unsigned max_segments, un
 extern "C" int fqgpu_ctx_set_seq_segment(fqgpu_ctx *ctx, unsigned symbols) {
   if (!ctx) return FQGPU_E_ARG;
   ctx->seq_segment = symbols;
+  if (symbols) {  // the power tables for this segment length (encode.hip rounds it the same way), before any encode uses them
+    int rc = use_device(ctx->device);
+    if (!rc) rc = fqgpu_sync(ctx);
+    if (rc) return rc;
+    const unsigned S = (unsigned)std::min((((size_t)symbols + 1023) / 1024) * 1024, (size_t)1 << 30);
+    if ((rc = fq_seq_pow_ensure(ctx->stream, ctx->tab[0], FQGPU_SEQ_MODELS, S))) return rc;
+    FQ_HIP(hipStreamSynchronize(ctx->stream));
+  }
   return FQGPU_OK;
 }
 

@@ -85,8 +85,12 @@ __device__ __forceinline__ unsigned seq_group_of(unsigned nf, unsigned qmax, uns
 }
 
 // plan[]: fitem_base[B+1] (step A workgroups before every context) | fseg_base[B+1] (functions
-// before every context) | seg_base[B+1] (segments) | eitem_base[B+1] (step C waves)
-constexpr unsigned SEGPLAN_WORDS = 4 * (SeqModel::B + 1) + 4;  // + the work counter of step A
+// before every context) | seg_base[B+1] (segments) | eitem_base[B+1] (step C waves) |
+// citem_base[B+1] (step B items: 64 groups each, for chains of more than SEQ_ITEM_GROUPS groups)
+constexpr unsigned SEGPLAN_WORDS = 5 * (SeqModel::B + 1) + 4;  // + the work counter of step A
+constexpr unsigned SEQ_ITEM_GROUPS = 64;
+// items of a chain with nl groups (0: the chain is short, k_seq_resolve walks its groups itself)
+__device__ __forceinline__ unsigned seq_items_of(unsigned nl) { return nl > SEQ_ITEM_GROUPS ? (nl + SEQ_ITEM_GROUPS - 1) / SEQ_ITEM_GROUPS : 0u; }
 
 __global__ void __launch_bounds__(256)
 k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, unsigned qmax, unsigned gmin, unsigned wpg,
@@ -97,17 +101,17 @@ k_seq_segplan(const uint32_t *__restrict__ arrays, unsigned S, unsigned qmax, un
   const unsigned n = arrays[c];
   s_nseg[c] = (n + S - 1) / S;
   __syncthreads();
-  unsigned fi = 0, fs = 0, sg = 0, ei = 0;
+  unsigned fi = 0, fs = 0, sg = 0, ei = 0, ci = 0;
   for (unsigned o = 0; o < c; o++) {
     const unsigned ns = s_nseg[o], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin), nl = (nf + Q - 1) / Q;
-    fi += (nl + wpg - 1) / wpg; fs += nf; sg += ns; ei += (ns + 63) / 64;
+    fi += (nl + wpg - 1) / wpg; fs += nf; sg += ns; ei += (ns + 63) / 64; ci += seq_items_of(nl);
   }
-  uint32_t *fitem = plan, *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *eitem = plan + 3 * (B + 1);
-  fitem[c] = fi; fseg[c] = fs; seg[c] = sg; eitem[c] = ei;
-  if (c == 0) plan[4 * (B + 1)] = 0;  // step A's work counter
+  uint32_t *fitem = plan, *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *eitem = plan + 3 * (B + 1), *citem = plan + 4 * (B + 1);
+  fitem[c] = fi; fseg[c] = fs; seg[c] = sg; eitem[c] = ei; citem[c] = ci;
+  if (c == 0) plan[5 * (B + 1)] = 0;  // step A's work counter
   if (c == B - 1) {
     const unsigned ns = s_nseg[c], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin), nl = (nf + Q - 1) / Q;
-    fitem[B] = fi + (nl + wpg - 1) / wpg; fseg[B] = fs + nf; seg[B] = sg + ns; eitem[B] = ei + (ns + 63) / 64;
+    fitem[B] = fi + (nl + wpg - 1) / wpg; fseg[B] = fs + nf; seg[B] = sg + ns; eitem[B] = ei + (ns + 63) / 64; citem[B] = ci + seq_items_of(nl);
   }
 }
 
@@ -285,7 +289,8 @@ template <unsigned PER0, bool TWO>
 __global__ void __launch_bounds__((TWO ? SETS_WAVES2 : SETS_WAVES) * 64, TWO ? 5 : 1)
 k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
               const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs,
-              const uint16_t *__restrict__ next, unsigned next_stride, unsigned S, unsigned qmax, unsigned gmin,
+              const uint16_t *__restrict__ next, unsigned next_stride, const uint16_t *__restrict__ pow, unsigned pow_stride,
+              unsigned S, unsigned qmax, unsigned gmin,
               unsigned rounds, unsigned fstride, uint16_t *__restrict__ fbuf, unsigned *__restrict__ work_counter) {
   constexpr unsigned WAVES = TWO ? SETS_WAVES2 : SETS_WAVES;
   extern __shared__ uint32_t lds[];  // next[4][size] (TWO: next2[16][size]) of this context
@@ -337,7 +342,41 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
       unsigned level = 0, n = size, n1 = 0;
       unsigned w = 0, stop = 1;  // merge points after 4, 16, 48, 128, 512, 2048, 8192, ... symbols
       uint4 cur = gseg[lane];
+      auto write_function = [&](unsigned j) {  // F_j[entry of the group] = state here, both as (state - size) * 2
+        uint16_t *f = fbuf + (size_t)(fseg[c] + s0 + j) * fstride;
+#pragma unroll
+        for (unsigned jj = 0; jj < PER0; jj++) {
+          const unsigned xi = lane + 64u * jj;
+          if (jj < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[jj] : L.list[L.m[x0[jj]]];
+        }
+      };
       for (unsigned blk = 0; blk < nblk; blk++) {
+        // A segment that is S times ONE symbol (a homopolymer context fed its own base) is a power of
+        // that symbol's transition: T_s^S from the handle's table, one lookup per carried state instead
+        // of S steps -- such a context is (nearly) a permutation of the states, nothing ever merges.
+        if (pow != nullptr && blk % sub_blocks == 0) {
+          const unsigned s_first = (unsigned)__builtin_amdgcn_readfirstlane(cur.x) & 3u, pat = s_first * 0x01010101u;
+          auto differs = [&](const uint4 v) { return (((v.x ^ pat) | (v.y ^ pat) | (v.z ^ pat) | (v.w ^ pat)) & 0x03030303u) != 0u; };
+          bool uni = __ballot(differs(cur)) == 0ull;
+          for (unsigned b = 1; uni && b < sub_blocks; b++) uni = __ballot(differs(gseg[(size_t)(blk + b) * 64 + lane])) == 0ull;
+          if (uni) {
+            const char *P = reinterpret_cast<const char *>(pow + (size_t)c * pow_stride + ((size_t)s_first << log));
+            if (level == 0) {
+#pragma unroll
+              for (unsigned j = 0; j < PER0; j++)
+                if (j < per) x0[j] = *reinterpret_cast<const uint16_t *>(P + x0[j]);
+            } else {
+              for (unsigned i = lane; i < n; i += 64) L.list[i] = *reinterpret_cast<const uint16_t *>(P + L.list[i]);
+              fq_lds_wave_sync();
+            }
+            blk += sub_blocks - 1;
+            w = (blk + 1) * (SETS_BLOCK / 4);
+            while (stop <= w) stop = stop == 1 ? 4 : stop == 4 ? 12 : stop == 12 ? 32 : stop * 4;  // merge points inside the segment are dropped
+            if (blk + 1 < nblk) cur = gseg[(size_t)(blk + 1) * 64 + lane];
+            write_function(blk / sub_blocks);
+            continue;
+          }
+        }
         const uint4 nxt = blk + 1 < nblk ? gseg[(size_t)(blk + 1) * 64 + lane] : cur;  // lands while cur is walked
         const unsigned wb_end = (blk + 1) * (SETS_BLOCK / 4);
         const uint4 rows = TWO ? sets_pack_rows(cur, log) : cur;
@@ -393,14 +432,7 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
           }
         }
         cur = nxt;
-        if ((blk + 1) % sub_blocks == 0) {  // F[entry] = state here, both as (state - size) * 2
-          uint16_t *f = fbuf + (size_t)(fseg[c] + s0 + blk / sub_blocks) * fstride;
-#pragma unroll
-          for (unsigned j = 0; j < PER0; j++) {
-            const unsigned xi = lane + 64u * j;
-            if (j < per && xi < size) f[xi] = level == 0 ? (uint16_t)x0[j] : L.list[L.m[x0[j]]];
-          }
-        }
+        if ((blk + 1) % sub_blocks == 0) write_function(blk / sub_blocks);
       }
       unsigned nk = 0;
       if (lane == 0) nk = atomicAdd(&s_next, 1u);
@@ -410,16 +442,18 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
 }
 
 // Step B: entry state of every segment of every chain.  The functions of a group all start at
-// the group's entry state, so a group costs one round of independent 2-byte loads.
-__global__ void __launch_bounds__(256)
-k_seq_resolve(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned qmax,
-              unsigned gmin, uint16_t *__restrict__ entry) {
-  constexpr unsigned B = SeqModel::B;
-  const uint32_t *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1);
-  const unsigned c = threadIdx.x;
-  const unsigned ns = seg[c + 1] - seg[c], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin);
-  unsigned xo = 0;  // FSE_initCState: state = size
-  for (unsigned s0 = 0; s0 < ns; s0 += Q) {
+// the group's entry state, so a group costs one round of independent 2-byte loads, and the chain
+// x <- F_last[x] runs from group to group.  A chain of more than SEQ_ITEM_GROUPS groups (one context
+// holding most of a block: 3 600 groups for 256 MiB of poly-A) is resolved in three levels over
+// ITEMS of 64 groups, like the quality stream's runs of opaque segments:
+//  k_seq_compose  one wave per item: the item's composed function for every possible entry state
+//  k_seq_resolve  one thread per context: short chain: group by group; long chain: item by item
+//  k_seq_expand   one thread per item of a long chain: group by group inside the item
+__device__ __forceinline__ unsigned seq_resolve_groups(const uint32_t *__restrict__ fseg, const uint32_t *__restrict__ seg,
+                                                       const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned c, unsigned Q,
+                                                       unsigned nf, unsigned ns, unsigned s_begin, unsigned s_end, unsigned xo,
+                                                       uint16_t *__restrict__ entry) {
+  for (unsigned s0 = s_begin; s0 < s_end; s0 += Q) {
     entry[seg[c] + s0] = (uint16_t)xo;
     unsigned v[SETS_MAX_GROUP];
 #pragma unroll
@@ -433,6 +467,70 @@ k_seq_resolve(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fb
       }
     xo = nx;
   }
+  (void)ns;
+  return xo;
+}
+
+template <unsigned PER0>
+__global__ void __launch_bounds__(64)
+k_seq_compose(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs, const uint16_t *__restrict__ fbuf,
+              unsigned fstride, unsigned qmax, unsigned gmin, uint16_t *__restrict__ cbuf) {
+  constexpr unsigned B = SeqModel::B;
+  const uint32_t *fseg = plan + (B + 1), *citem = plan + 4 * (B + 1);
+  const unsigned item = blockIdx.x, lane = fq_lane();
+  if (item >= citem[B]) return;  // the grid is an upper bound
+  const unsigned c = seq_item_ctx(citem, item);
+  const unsigned nf = fseg[c + 1] - fseg[c], Q = seq_group_of(nf, qmax, gmin), nl = (nf + Q - 1) / Q;
+  const unsigned g0 = (item - citem[c]) * SEQ_ITEM_GROUPS, g1 = min(g0 + SEQ_ITEM_GROUPS, nl);
+  const unsigned size = 1u << logs[c], per = max(size >> 6, 1u);
+  unsigned x[PER0];  // (state - size) * 2 behind the groups walked so far, for every entry state of the item
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) x[j] = ((lane + 64u * j) & (size - 1)) * 2u;
+  for (unsigned g = g0; g < g1; g++) {
+    const unsigned last = min(g * Q + Q, nf) - 1;  // the group's last function: entry of the group -> entry of the next
+    const uint16_t *f = fbuf + (size_t)(fseg[c] + last) * fstride;
+#pragma unroll
+    for (unsigned j = 0; j < PER0; j++)
+      if (j < per) x[j] = f[x[j] >> 1];
+  }
+  uint16_t *o = cbuf + (size_t)item * fstride;
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) {
+    const unsigned xi = lane + 64u * j;
+    if (j < per && xi < size) o[xi] = (uint16_t)x[j];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_seq_resolve(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned qmax,
+              unsigned gmin, const uint16_t *__restrict__ cbuf, uint16_t *__restrict__ item_entry, uint16_t *__restrict__ entry) {
+  constexpr unsigned B = SeqModel::B;
+  const uint32_t *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *citem = plan + 4 * (B + 1);
+  const unsigned c = threadIdx.x;
+  const unsigned ns = seg[c + 1] - seg[c], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin);
+  const unsigned ni = citem[c + 1] - citem[c];
+  unsigned xo = 0;  // FSE_initCState: state = size
+  if (ni == 0) {
+    (void)seq_resolve_groups(fseg, seg, fbuf, fstride, c, Q, nf, ns, 0, ns, xo, entry);
+  } else {
+    for (unsigned i = 0; i < ni; i++) {
+      item_entry[citem[c] + i] = (uint16_t)xo;
+      if (i + 1 < ni) xo = cbuf[(size_t)(citem[c] + i) * fstride + (xo >> 1)];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_seq_expand(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned qmax,
+             unsigned gmin, const uint16_t *__restrict__ item_entry, uint16_t *__restrict__ entry) {
+  constexpr unsigned B = SeqModel::B;
+  const uint32_t *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *citem = plan + 4 * (B + 1);
+  const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= citem[B]) return;  // the grid is an upper bound
+  const unsigned c = seq_item_ctx(citem, item);
+  const unsigned ns = seg[c + 1] - seg[c], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin);
+  const unsigned s_begin = (item - citem[c]) * SEQ_ITEM_GROUPS * Q, s_end = min(s_begin + SEQ_ITEM_GROUPS * Q, ns);
+  (void)seq_resolve_groups(fseg, seg, fbuf, fstride, c, Q, nf, ns, s_begin, s_end, item_entry[item], entry);
 }
 
 // Step C: one lane per segment, 64 segments of one context per wave

@@ -119,7 +119,8 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   uint4 (*kb4)[TS_BATCH / 8] = reinterpret_cast<uint4 (*)[TS_BATCH / 8]>(stage_raw);
   uint4 (*sb4)[QUAL ? TS_BATCH / 16 : 1] = reinterpret_cast<uint4 (*)[QUAL ? TS_BATCH / 16 : 1]>(stage_raw + KB_BYTES);
   TsRunMap &rm = *reinterpret_cast<TsRunMap *>(stage_raw);
-  __shared__ unsigned wsum[TS_WAVES], s_cnt[NCHUNK < 2 ? 2 : NCHUNK], s_nruns;
+  __shared__ unsigned wsum[TS_WAVES], s_cnt[NCHUNK < 2 ? 2 : NCHUNK], s_nruns, s_max;
+  __shared__ uint32_t dummy[64];  // where the lanes of the combining ranker that are no run heads send their (empty) atomics
   uint16_t *cur16 = reinterpret_cast<uint16_t *>(cursor32);
   const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), tid = threadIdx.x, wave = tid >> 6, lane = fq_lane();
   const unsigned e0 = tile * TS_TILE, nt = min(TS_TILE, n_sym - e0);
@@ -132,13 +133,16 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
     uint32_t *h32 = reinterpret_cast<uint32_t *>(lsym);  // B * 4 <= TS_TILE bytes
     static_assert(B * 4 <= TS_TILE, "histogram row fits the symbol staging area");
     for (unsigned c = tid; c < B; c += TS_THREADS) h32[c] = hrow[c];
+    if (tid == 0) s_max = 0;
+    if (tid < 64) dummy[tid] = 0;
     __syncthreads();
     constexpr unsigned CPT = B >= TS_THREADS ? B / TS_THREADS : 1;  // contexts per thread
     const unsigned c0 = tid * CPT;
-    unsigned sum = 0;
+    unsigned sum = 0, mx = 0;
     if (c0 < B)
 #pragma unroll
-      for (unsigned k = 0; k < CPT; k++) sum += h32[c0 + k];
+      for (unsigned k = 0; k < CPT; k++) { sum += h32[c0 + k]; mx = max(mx, h32[c0 + k]); }
+    if (mx * 8u >= nt) atomicMax(&s_max, mx);  // (rare: only a context that holds an eighth of the tile reports)
     unsigned tot;
     unsigned run = ts_block_scan<TS_THREADS>(sum, wsum, &tot);
     if (c0 < B) {
@@ -185,8 +189,53 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   }
   if (wave != 0 && nbatch > 1) request(1);
   __syncthreads();
+  // One context with an eighth of the tile or more: its symbols meet on ONE cursor, and same-address
+  // LDS atomics of an instruction are served one lane after the other (binned qualities: the partition
+  // of a tile took twice as long, one quality everywhere: sixteen times).  Such data comes in RUNS --
+  // neighbouring symbols share the context -- so the combining ranker lets the first lane of every run
+  // add the run's length and hands the result down the run.  More instructions per symbol, hence
+  // only for such tiles; the ranks are the same numbers either way.
+  const bool combine = s_max * 8u >= nt;
+  const unsigned long long lanes_le = (2ull << lane) - 1ull;
   for (unsigned j = 0; j < nbatch; j++) {
-    if (wave == 0) {
+    if (wave == 0 && combine) {
+      const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j % NBUF]);
+      const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j % NBUF]);
+      uint16_t *gpos = lpos16 + e0 + j * TS_BATCH;
+      const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
+      constexpr unsigned G = 8;
+      for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // wave-uniform trip count, branch-free, as below
+        unsigned key[G], pos[G], sy[G], head_of[G];
+#pragma unroll
+        for (unsigned g = 0; g < G; g++) {
+          const unsigned i = cb + 64 * g + lane;
+          key[g] = kb[i];
+          sy[g] = QUAL ? (unsigned)sb[i] : key[g] >> 8;
+        }
+#pragma unroll
+        for (unsigned g = 0; g < G; g++) {
+          const bool on = cb + 64 * g + lane < nb;
+          const unsigned c = on ? (QUAL ? key[g] : key[g] & 0xFFu) : 0xFFFFFFFFu;  // lanes beyond the batch: a run of their own
+          const unsigned left = (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)c, 0x138, 0xF, 0xF, false);  // lane - 1's context (wave_shr:1)
+          const unsigned long long heads = __ballot(c != left);  // (lane 0 is one)
+          const unsigned long long le = heads & lanes_le, gt = heads & ~lanes_le;
+          const unsigned h = 63u - (unsigned)__clzll((long long)le);
+          const unsigned nx = gt ? (unsigned)__ffsll((long long)gt) - 1u : 64u;
+          const bool act = on && h == lane;
+          const unsigned sh = 16u * (c & 1u);
+          uint32_t *a = act ? &cursor32[c >> 1] : &dummy[lane];
+          pos[g] = (atomicAdd(a, act ? (nx - lane) << sh : 0u) >> sh) & 0xFFFFu;
+          head_of[g] = h;
+        }
+#pragma unroll
+        for (unsigned g = 0; g < G; g++) {
+          const unsigned i = cb + 64 * g + lane;
+          const unsigned p = (unsigned)__shfl((int)pos[g], (int)head_of[g]) + (lane - head_of[g]);
+          gpos[i] = (uint16_t)p;
+          lsym[i < nb ? p : TS_TILE + lane] = (uint8_t)sy[g];
+        }
+      }
+    } else if (wave == 0) {
       const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j % NBUF]);
       const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j % NBUF]);
       uint16_t *gpos = lpos16 + e0 + j * TS_BATCH;  // the ranking wave stores the positions itself: 128 contiguous bytes per instruction

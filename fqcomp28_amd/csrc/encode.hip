@@ -183,6 +183,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if (serial_seq) {
     if ((rc = sc.seq_plan.reserve((size_t)SEGPLAN_WORDS * 4 + (size_t)seq_max_segs * 2 + 64))) return rc;
     if ((rc = sc.seq_fbuf.reserve((size_t)seq_max_segs * seq_fstride * 2 + 64))) return rc;
+    if ((rc = sc.seq_cbuf.reserve((size_t)(seq_max_segs / SEQ_ITEM_GROUPS + B + 1) * (seq_fstride * 2 + 2) + 64))) return rc;
   }
   if (serial_seq && (rc = sc.seq_bdesc.reserve((size_t)(n_ptiles + 1) * SeqModel::B * 6 + 64))) return rc;
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
@@ -263,6 +264,11 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     const unsigned Q = min(max(ctx->seq_group, 1u), SETS_MAX_GROUP), gmin = max(ctx->seq_group_min, 1u);
     const unsigned rounds = max(SETS_ROUNDS / Q, 1u);
     const unsigned max_fitems = seq_max_segs / (wpg * rounds) + B + 1, max_eitems = seq_max_segs / 64 + B + 1;
+    const unsigned max_citems = seq_max_segs / SEQ_ITEM_GROUPS + B + 1;
+    uint16_t *cbuf = sc.seq_cbuf.as<uint16_t>(), *item_entry = cbuf + (size_t)max_citems * seq_fstride;
+    const uint16_t *pow = nullptr;  // power tables for this segment length (uniform segments), if the handle has them
+    for (unsigned i = 0; i < FQ_SEQ_POW_SETS; i++)
+      if (tab.seq_pow[i] && tab.seq_pow_S[i] == seq_S) pow = tab.seq_pow[i];
     static const bool dbg_skip = fq_debug_flag("FQGPU_DEBUG_SKIP_SEQ_CHAIN");  // timing experiment only: wrong output
     if (!dbg_off) hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, Q, gmin, wpg * rounds, plan);
     FQ_SPAN_END();
@@ -272,14 +278,21 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
       } else if (two)
         hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(min(max_fitems, ctx->setfunc_wgs ? ctx->setfunc_wgs : ctx->n_cus)), dim3(SETS_WAVES2 * 64),
                            32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2,
-                           4 * next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 4 * (B + 1));
+                           4 * next_stride, pow, next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 5 * (B + 1));
       else
         hipLaunchKernelGGL((k_seq_setfunc<64, false>), dim3(min(max_fitems, 2 * ctx->n_cus)), dim3(SETS_WAVES * 64),
                            8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1,
-                           next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 4 * (B + 1));
+                           next_stride, pow, next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 5 * (B + 1));
       FQ_SPAN_END();
       FQ_SPAN_BEGIN("seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
-      if (!dbg_off) hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, Q, gmin, entry);
+      if (!dbg_off) {
+        if (tab.max_log <= 11)
+          hipLaunchKernelGGL(k_seq_compose<32>, dim3(max_citems), dim3(64), 0, st, plan, tab.logs, fbuf, seq_fstride, Q, gmin, cbuf);
+        else
+          hipLaunchKernelGGL(k_seq_compose<64>, dim3(max_citems), dim3(64), 0, st, plan, tab.logs, fbuf, seq_fstride, Q, gmin, cbuf);
+        hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, Q, gmin, cbuf, item_entry, entry);
+        hipLaunchKernelGGL(k_seq_expand, dim3((max_citems + 63) / 64), dim3(64), 0, st, plan, fbuf, seq_fstride, Q, gmin, item_entry, entry);
+      }
       FQ_SPAN_END();
       FQ_SPAN_BEGIN("seq.chains");  dbg_off = (dbg_mask & 8u) != 0;
       if (!dbg_off) hipLaunchKernelGGL(k_seq_emit, dim3(max_eitems), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),

@@ -46,9 +46,12 @@ struct DevTables {
                                 // next[s][x - size] = ((state after coding s in state x) - size) * 2
   uint16_t *next2 = nullptr;    // sequence stream, max_log <= 11: [B][16 << max_log] two-symbol tables,
                                 // next2[s1 | s2 << 2][x - size] = next[s2][next[s1][x - size]]
+  uint16_t *seq_pow[4] = {nullptr, nullptr, nullptr, nullptr};  // sequence stream: next1-shaped tables of S-fold powers,
+  unsigned seq_pow_S[4] = {0, 0, 0, 0};                         // pow[s][x - size] = next[s]^S, for the S named here
   uint32_t max_log = 0;
   size_t ct_words = 0, dt_words = 0;
 };
+#define FQ_SEQ_POW_SETS 4
 
 // Result block of one (block, stream) coding job, in device memory.
 struct StreamResult {
@@ -115,6 +118,7 @@ struct EncScratch {
   DevBuf seq_bdesc;   // sequence stream: batch descriptors of the batch-sorted partition (encode.hip: SeqBatchDesc)
   DevBuf seq_plan;    // segment plan of the sequence chains (encode.hip: SEGPLAN_WORDS) + entry states
   DevBuf seq_fbuf;    // u16 [segments][1 << max_log] segment functions F: entry state -> exit state
+  DevBuf seq_cbuf;    // sequence stream: composed functions and entry states of the items of long chains (k_seq_compose)
   DevBuf tile_bits;   // u32 [ptiles]
   DevBuf tile_bit_base;  // u64 [ptiles+1]
   DevBuf dbg_enc16;   // timing experiments only (FQGPU_DEBUG_NO_ALIAS): enc16 apart from the keys, so that stale keys stay valid
@@ -217,6 +221,7 @@ int fq_build_freq_tables(int device, hipStream_t st, const uint8_t *raw_dev, con
 int fq_normalize_counts(hipStream_t st, const uint32_t *counts_dev, int n_models, int alpha,
                         int16_t *norm_dev, uint32_t *logs_dev, uint32_t *max_log_dev, uint32_t *err_dev);
 int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint32_t *err_dev);
+int fq_seq_pow_ensure(hipStream_t st, DevTables &t, unsigned n_models, unsigned S);
 
 // wait: event the lane's first kernel waits for (inputs arriving on another stream), or nullptr;
 // done: receives the stream on which the block's last kernel was launched (copies of the results

@@ -454,6 +454,36 @@ k_build_seq_next2(const uint32_t *__restrict__ logs, const uint16_t *__restrict_
   }
 }
 
+// S-fold powers of the one-symbol transitions: pow[s][xi] = next[s] applied S times to xi (same
+// pre-scaling): the function of a chain segment that is S times the symbol s (k_seq_setfunc).
+// Square and multiply over the bits of S, one workgroup per (context, symbol).
+__global__ void __launch_bounds__(256)
+k_build_seq_pow(const uint32_t *__restrict__ logs, const uint16_t *__restrict__ next1, unsigned stride, unsigned S,
+                uint16_t *__restrict__ pow) {
+  __shared__ uint16_t base[1 << 12], acc[1 << 12], tmp[1 << 12];
+  const unsigned c = blockIdx.x, s = blockIdx.y;
+  const unsigned log = logs[c], size = 1u << log;
+  const uint16_t *n1 = next1 + (size_t)c * stride + ((size_t)s << log);
+  for (unsigned i = threadIdx.x; i < size; i += blockDim.x) { base[i] = (uint16_t)(n1[i] >> 1); acc[i] = (uint16_t)i; }
+  __syncthreads();
+  for (unsigned e = S; e; e >>= 1) {
+    if (e & 1u) {
+      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) tmp[i] = base[acc[i]];
+      __syncthreads();
+      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) acc[i] = tmp[i];
+      __syncthreads();
+    }
+    if (e > 1u) {
+      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) tmp[i] = base[base[i]];
+      __syncthreads();
+      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) base[i] = tmp[i];
+      __syncthreads();
+    }
+  }
+  uint16_t *o = pow + (size_t)c * stride + ((size_t)s << log);
+  for (unsigned i = threadIdx.x; i < size; i += blockDim.x) o[i] = (uint16_t)(acc[i] * 2u);
+}
+
 // symbols with normalised count 1 or -1 ("reset" symbols of the chain kernels, encode.hip)
 __global__ void __launch_bounds__(256)
 k_reset_masks(const int16_t *__restrict__ norm, unsigned B, unsigned A, unsigned long long *__restrict__ mask) {
@@ -465,6 +495,27 @@ k_reset_masks(const int16_t *__restrict__ norm, unsigned B, unsigned A, unsigned
     if (v == 1 || v == -1) m |= 1ull << s;
   }
   mask[c] = m;
+}
+
+// Power tables of the sequence contexts for segments of S symbols (kept per handle for a few S:
+// the three default segment lengths and the last one set by hand).  Launched on st; the caller
+// orders it against the encodes that use it.
+int fq_seq_pow_ensure(hipStream_t st, DevTables &t, unsigned n_models, unsigned S) {
+  if (!t.next1 || S == 0) return FQGPU_OK;
+  for (unsigned i = 0; i < FQ_SEQ_POW_SETS; i++)
+    if (t.seq_pow[i] && t.seq_pow_S[i] == S) return FQGPU_OK;
+  unsigned slot = FQ_SEQ_POW_SETS - 1;  // the last slot is the one that gets replaced
+  for (unsigned i = 0; i < FQ_SEQ_POW_SETS; i++)
+    if (!t.seq_pow[i]) { slot = i; break; }
+  const unsigned stride = 4u << t.max_log;
+  if (!t.seq_pow[slot]) {
+    t.seq_pow[slot] = fq_dev_alloc<uint16_t>((size_t)n_models * stride + 64);
+    if (!t.seq_pow[slot]) return FQGPU_E_NOMEM;
+  }
+  t.seq_pow_S[slot] = S;
+  hipLaunchKernelGGL(k_build_seq_pow, dim3(n_models, 4), dim3(256), 0, st, t.logs, t.next1, stride, S, t.seq_pow[slot]);
+  FQ_HIP(hipGetLastError());
+  return FQGPU_OK;
 }
 
 // t.norm and t.logs are already on the device; allocates and fills everything else
@@ -506,6 +557,10 @@ int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint3
       t.next2 = fq_dev_alloc<uint16_t>((size_t)B * 4 * stride + 64);
       if (!t.next2) return FQGPU_E_NOMEM;
       hipLaunchKernelGGL(k_build_seq_next2, dim3(B), dim3(256), 0, st, t.logs, t.next1, stride, 4 * stride, t.next2);
+    }
+    for (unsigned S : {1024u, 2048u, 4096u}) {  // the default segment lengths of the sequence chains (encode.hip: auto_seq_S)
+      const int rc = fq_seq_pow_ensure(st, t, B, S);
+      if (rc) return rc;
     }
   }
   FQ_HIP(hipGetLastError());
