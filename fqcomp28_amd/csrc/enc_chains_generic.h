@@ -27,11 +27,6 @@ constexpr unsigned SEG_SLOT = 16;  // lanes of one candidate walk: four walks sh
 // segment table of one stream (all arrays indexed by the global segment number)
 struct SegArrays {
   uint32_t *anchor;       // offset of the anchor symbol inside the segment (cls 1 .. 64), the symbol (uniform), or SEG_NONE
-  uint32_t *fidx;         // function slot of a segment whose successor needs one, or SEG_NONE
-  uint32_t *olist;        // segments that get a full function from k_seg_setfunc, in no particular order
-  uint32_t *tlist;        // candidate walks behind an anchor: segment * 4 + quarter (16 candidates each)
-  uint32_t *hlist;        // candidate walks up to an anchor: segment * 4 + quarter of the predecessor's candidates
-  uint32_t *counts;       // lengths of olist, tlist, hlist
   uint32_t *usym;         // [B] the symbol whose power table the context owns in this block, or SEG_NONE
   uint16_t *entry_state;  // state in front of the first symbol of every segment
   uint16_t *cand_exit;    // [segment][64] state at the end of the segment for every candidate of its anchor
@@ -111,7 +106,8 @@ k_seg_scan(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ 
     if (found != SEG_NONE) { cls = 1; anchor = found; }
     else if ((best >> 20) <= SEG_MAX_CAND) { cls = best >> 20; anchor = best & 0xFFFFFu; }
     else if (uniform) {  // one power table per context and block: the first symbol to ask gets it
-      const unsigned old = atomicCAS(&sa.usym[c], SEG_NONE, s0);
+      unsigned old = __hip_atomic_load(&sa.usym[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a chain of uniform segments: one CAS, not thousands on one word)
+      if (old == SEG_NONE) old = atomicCAS(&sa.usym[c], SEG_NONE, s0);
       if (old == SEG_NONE || old == s0) { cls = SEG_CLS_UNIFORM; anchor = s0; }
     }
     sa.cls[seg] = (uint8_t)cls;
@@ -120,88 +116,80 @@ k_seg_scan(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ 
   }
 }
 
-// One thread per segment: who computes the function of a segment whose successor needs one.
-//   opaque                          -> k_seg_setfunc (olist), slot = the segment
+// Who computes the function of a segment whose successor needs one:
+//   opaque                          -> k_seg_setfunc, slot = the segment
 //   uniform                         -> the context's power table (slot pbase + context)
-//   anchored, 2 .. 64 candidates    -> k_seg_tails walks every candidate to the end of the segment;
-//       k_seg_heads walks every state the segment can be entered with up to the anchor -- possible
+//   anchored, 2 .. 64 candidates    -> k_seg_cand<false> walks every candidate to the end of the segment;
+//       k_seg_cand<true> walks every state the segment can be entered with up to the anchor -- possible
 //       when the predecessor is anchored too (its candidates' exits) or the chain starts here;
 //       behind an opaque or uniform segment the entry state can be anything: k_seg_setfunc
 //   reset symbol (1 candidate)      -> nothing: k_seg_walk<1> knows the exit state
-template <class M>
-__global__ void __launch_bounds__(256)
-k_seg_plan(const uint32_t *__restrict__ arrays, unsigned pbase, SegArrays sa) {
-  constexpr unsigned B = M::B;
-  const uint32_t *seg_base = arrays + B + (B + 1);
-  const unsigned seg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= seg_base[B]) return;
-  const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
-  const unsigned nseg = seg_base[c + 1] - seg_base[c];
+// seg_wants_*: the same decisions for the kernels that act on them (k: index in the chain).
+__device__ __forceinline__ bool seg_is_cand(unsigned cls) { return cls >= 2 && cls <= SEG_MAX_CAND; }
+__device__ __forceinline__ bool seg_entry_known(unsigned k, unsigned pred_cls) {  // ... to be one of <= 64 states
+  return k == 0 || pred_cls == 1 || seg_is_cand(pred_cls);
+}
+
+// function slot of segment k of a chain of nseg (slot = the segment itself; the power tables follow
+// behind the last segment's slot), or SEG_NONE: reset symbol inside, or nothing follows
+__device__ __forceinline__ unsigned seg_fslot(const SegArrays &sa, unsigned seg, unsigned k, unsigned nseg, unsigned c,
+                                              unsigned pbase) {
+  if (k + 1 >= nseg) return SEG_NONE;
   const unsigned cls = sa.cls[seg];
-  unsigned slot = SEG_NONE;
-  if (k + 1 < nseg && cls != 1) {
-    bool full = cls == SEG_CLS_OPAQUE;
-    if (cls == SEG_CLS_UNIFORM) {
-      slot = pbase + c;
-    } else {
-      slot = seg;
-      if (!full) {
-        const unsigned nq = (cls + SEG_SLOT - 1) / SEG_SLOT;
-        const unsigned t0 = atomicAdd(&sa.counts[1], nq);
-        for (unsigned q = 0; q < nq; q++) sa.tlist[t0 + q] = seg * 4 + q;
-        const unsigned pred = k ? (unsigned)sa.cls[seg - 1] : 1u;
-        if (pred == SEG_CLS_OPAQUE || pred == SEG_CLS_UNIFORM) {
-          full = true;
-        } else {
-          const unsigned nh = (pred + SEG_SLOT - 1) / SEG_SLOT;
-          const unsigned h0 = atomicAdd(&sa.counts[2], nh);
-          for (unsigned q = 0; q < nh; q++) sa.hlist[h0 + q] = seg * 4 + q;
-        }
-      }
-      if (full) sa.olist[atomicAdd(&sa.counts[0], 1u)] = seg;
-    }
-  }
-  sa.fidx[seg] = slot;
+  return cls == 1 ? SEG_NONE : cls == SEG_CLS_UNIFORM ? pbase + c : seg;
+}
+// does k_seg_setfunc compute the function of this segment?
+__device__ __forceinline__ bool seg_wants_setfunc(const SegArrays &sa, unsigned seg, unsigned k, unsigned nseg) {
+  if (k + 1 >= nseg) return false;
+  const unsigned cls = sa.cls[seg];
+  return cls == SEG_CLS_OPAQUE || (seg_is_cand(cls) && !seg_entry_known(k, k ? (unsigned)sa.cls[seg - 1] : 1u));
 }
 
 // T_s^S for the context's uniform symbol s: the function of a segment that is S times s, by
-// square and multiply over the bits of S.  Slot pbase + context of the function buffer.
-template <class M>
-__global__ void __launch_bounds__(256)
-k_seg_pow(const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, unsigned S, unsigned pbase,
-          unsigned fstride, SegArrays sa, uint16_t *__restrict__ fbuf) {
-  __shared__ uint16_t base[1 << 12], acc[1 << 12], tmp[1 << 12];
-  const unsigned c = blockIdx.x;
-  const unsigned s = sa.usym[c];
-  if (s == SEG_NONE) return;  // (uniform)
-  const uint32_t *tbl = ct + ct_off[c];
-  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log;
+// square and multiply over the bits of S.  Slot pbase + context of the function buffer.  One wave
+// (a role of k_seg_setfunc's launch): the running power in registers, the base in LDS.
+template <class M, unsigned PER0>
+__device__ __forceinline__ void seg_pow_table(uint32_t *lds, const uint32_t *__restrict__ tbl, unsigned s, unsigned S,
+                                              uint16_t *__restrict__ f) {
+  const unsigned log = tbl[0] & 0xFFFFu, size = 1u << log, lane = fq_lane(), per = max(size >> 6, 1u);
   const uint16_t *st = reinterpret_cast<const uint16_t *>(tbl) + 2;
   const uint32_t *tt = tbl + 1 + (size >> 1);
   const int dfs = (int)tt[2 * s];
   const unsigned dnb = tt[2 * s + 1];
-  for (unsigned i = threadIdx.x; i < size; i += blockDim.x) {
-    const unsigned x = size + i, nb = (x + dnb) >> 16;
-    base[i] = (uint16_t)(st[(int)(x >> nb) + dfs] - size);
-    acc[i] = (uint16_t)i;
+  uint16_t *base = reinterpret_cast<uint16_t *>(lds);  // 2^log entries: fits the CTable's staging area
+  unsigned acc[PER0], tmp[PER0];
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) {
+    const unsigned i = (lane + 64u * j) & (size - 1);
+    acc[j] = i;
+    if (j < per) {
+      const unsigned x = size + i, nb = (x + dnb) >> 16;
+      base[i] = (uint16_t)(st[(int)(x >> nb) + dfs] - size);
+    }
   }
-  __syncthreads();
+  fq_lds_wave_sync();
   for (unsigned e = S; e; e >>= 1) {
     if (e & 1u) {
-      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) tmp[i] = base[acc[i]];
-      __syncthreads();
-      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) acc[i] = tmp[i];
-      __syncthreads();
+#pragma unroll
+      for (unsigned j = 0; j < PER0; j++)
+        if (j < per) acc[j] = base[acc[j]];
     }
     if (e > 1u) {
-      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) tmp[i] = base[base[i]];
-      __syncthreads();
-      for (unsigned i = threadIdx.x; i < size; i += blockDim.x) base[i] = tmp[i];
-      __syncthreads();
+#pragma unroll
+      for (unsigned j = 0; j < PER0; j++)
+        if (j < per) tmp[j] = base[base[(lane + 64u * j) & (size - 1)]];
+      fq_lds_wave_sync();  // every lane has read the old base
+#pragma unroll
+      for (unsigned j = 0; j < PER0; j++)
+        if (j < per) base[(lane + 64u * j) & (size - 1)] = (uint16_t)tmp[j];
+      fq_lds_wave_sync();
     }
   }
-  uint16_t *f = fbuf + (size_t)(pbase + c) * fstride;
-  for (unsigned i = threadIdx.x; i < size; i += blockDim.x) f[i] = (uint16_t)(size + acc[i]);
+#pragma unroll
+  for (unsigned j = 0; j < PER0; j++) {
+    const unsigned i = lane + 64u * j;
+    if (j < per && i < size) f[i] = (uint16_t)(size + acc[j]);
+  }
 }
 
 // symbols [i, end) of a context's run walked from state x: packed (nb, bits) into out, 16
@@ -243,16 +231,13 @@ __device__ __forceinline__ unsigned seg_walk_range(const LdsCTable &t, const uin
 // PASS 2: lane = segment, its head up to and including the first reset symbol (transparent) or
 //         all of it (every other class), from the resolved entry state.
 template <class M, int PASS>
-__global__ void __launch_bounds__(64)
-k_seg_walk(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
-           const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
-           const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state, unsigned S,
-           SegArrays sa, StreamResult *res) {
-  extern __shared__ uint32_t lds[];
+__device__ __forceinline__ void seg_walk_role(uint32_t *lds, unsigned item, const uint8_t *__restrict__ sorted_sym,
+                                              uint16_t *__restrict__ out16, const uint32_t *__restrict__ arrays,
+                                              const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off,
+                                              uint16_t *__restrict__ final_state, unsigned S, const SegArrays &sa, StreamResult *res) {
   constexpr unsigned B = M::B;
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
                  *item_base = seg_base + B + 1;
-  const unsigned item = blockIdx.x;
   if (item >= item_base[B]) return;  // the grid is an upper bound
   const unsigned c = seg_ctx_of<M>(item_base, item);
   const unsigned n = ctx_count[c];
@@ -281,30 +266,29 @@ k_seg_walk(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
   if (PASS == 2 && fq_lane() == 0) atomicMax(&res->refixed, min(S, n));
 }
 
+template <class M, int PASS>
+__global__ void __launch_bounds__(64)
+k_seg_walk(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16,
+           const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
+           const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state, unsigned S,
+           SegArrays sa, StreamResult *res) {
+  extern __shared__ uint32_t lds[];
+  seg_walk_role<M, PASS>(lds, blockIdx.x, sorted_sym, out16, arrays, ct, ct_off, final_state, S, sa, res);
+}
+
 // ---- anchored segments without a reset symbol: candidate walks ------------------------------
 // A symbol with n table cells leaves the coder in one of n states whatever it was in: cell j of the
 // symbol, j = (x >> nb) - n (zstd fse.h: FSE_encodeSymbol lands on stateTable[(x >> nb) +
 // deltaFindState], deltaFindState = first cell - n).  n = 1 is the reset symbol above; for
 // n <= 64 one lane per candidate walks on from the anchor:
-//   k_seg_tails  to the end of the segment: cand_exit[segment][j]
+//   tails (a role of k_seg_stage1)  to the end of the segment: cand_exit[segment][j]
 //   k_seg_heads  from every state the segment can be ENTERED with -- the predecessor's cand_exit,
 //                or the one known entry state behind a reset symbol / at the start of the chain --
 //                up to the anchor: which candidate that is, hence F[entry state] = cand_exit[that]
 // F has 2^log entries like a function of k_seg_setfunc, but only the (at most 64) entries that can
 // occur are written; k_seg_compose / k_seg_resolve2/3 treat it like any other function.  Sixteen
-// lanes per walk and four walks per wave, each with its own context's CTable in LDS: a block of
-// binned qualities costs n / 64 of a gather per symbol instead of the 1 .. 32 of the state sets.
-__device__ __forceinline__ LdsCTable slot_ctable(uint32_t *mine, const uint32_t *__restrict__ tbl, unsigned j, unsigned A) {
-  const unsigned log = tbl[0] & 0xFFFFu;
-  const unsigned words = 1u + (1u << (log - 1)) + 2u * A;
-  for (unsigned i = j; i < words; i += SEG_SLOT) mine[i] = tbl[i];
-  LdsCTable t;
-  t.log = log;
-  t.state_table = reinterpret_cast<const uint16_t *>(mine) + 2;
-  t.tt = mine + 1 + (1u << (log - 1));
-  return t;
-}
-
+// lanes per walk and four walks per wave: a block of binned qualities costs n / 64 of a gather
+// per symbol instead of the 1 .. 32 of the state sets.
 // symbols [i, end) of a run walked from state x, nothing written; returns the final state
 template <class M>
 __device__ __forceinline__ unsigned seg_state_range(const LdsCTable &t, const uint8_t *__restrict__ sym, unsigned i,
@@ -331,49 +315,71 @@ __device__ __forceinline__ unsigned seg_state_range(const LdsCTable &t, const ui
   return x;
 }
 
+// Four consecutive segments per wave (sixteen lanes each); they nearly always belong to one chain, so
+// the wave stages ONE CTable at a time and serves the slots of that context (4.6 KB of LDS per wave
+// instead of four tables: four times the waves per CU, and these walks are latency chains).
 template <class M, bool HEADS>
-__global__ void __launch_bounds__(64)
-k_seg_cand(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
-           const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, unsigned S, unsigned slot_words,
-           unsigned fstride, SegArrays sa, uint16_t *__restrict__ fbuf) {
-  extern __shared__ uint32_t lds[];
-  constexpr unsigned B = M::B;
+__device__ __forceinline__ void seg_cand_role(uint32_t *lds, unsigned w_first, unsigned w_step, const uint8_t *__restrict__ sorted_sym,
+                                              const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
+                                              const uint32_t *__restrict__ ct_off, unsigned S, unsigned fstride, const SegArrays &sa,
+                                              uint16_t *__restrict__ fbuf) {
+  constexpr unsigned B = M::B, PER = 64 / SEG_SLOT;
   const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
-  const unsigned n_entries = HEADS ? sa.counts[2] : sa.counts[1];
-  const uint32_t *list = HEADS ? sa.hlist : sa.tlist;
+  const unsigned n_segs = seg_base[B];
   const unsigned lane = fq_lane(), slot = lane / SEG_SLOT, j = lane % SEG_SLOT;
-  uint32_t *mine = lds + slot * slot_words;
-  for (unsigned w = blockIdx.x; w * (64 / SEG_SLOT) < n_entries; w += gridDim.x) {
-    const unsigned ei = w * (64 / SEG_SLOT) + slot;
-    fq_lds_wave_sync();  // the previous round's tables are no longer read
-    if (ei >= n_entries) continue;  // (whole slots; the loop bound is uniform)
-    const unsigned e = list[ei], seg = e >> 2, q = e & 3u;
-    const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
-    const LdsCTable t = slot_ctable(mine, ct + ct_off[c], j, M::A);
-    fq_lds_wave_sync();
-    const unsigned size = 1u << t.log;
-    const unsigned n = ctx_count[c], begin = k * S, end = min(n, begin + S);
-    const uint8_t *sym = sorted_sym + ctx_start[c];
-    const unsigned r = begin + sa.anchor[seg], cells = sa.cls[seg];
-    const unsigned s = sym[r] & (unsigned)(M::A - 1);
-    const int dfs = (int)t.tt[2 * s];
-    if (!HEADS) {
-      const unsigned cand = q * SEG_SLOT + j;
-      if (cand >= cells) continue;
-      unsigned x = t.state_table[dfs + (int)cells + (int)cand];
-      x = seg_state_range<M>(t, sym, r + 1, end, x);
-      sa.cand_exit[(size_t)seg * SEG_MAX_CAND + cand] = (uint16_t)x;
-    } else {
-      const unsigned pred = k ? (unsigned)sa.cls[seg - 1] : 1u;
-      const unsigned cand = q * SEG_SLOT + j;
-      if (cand >= pred) continue;
-      const unsigned entry = pred == 1 ? (unsigned)sa.entry_state[seg] : (unsigned)sa.cand_exit[(size_t)(seg - 1) * SEG_MAX_CAND + cand];
-      const unsigned x = seg_state_range<M>(t, sym, begin, r, entry);
-      const unsigned nb = (x + t.tt[2 * s + 1]) >> 16;
-      const unsigned u = (x >> nb) - cells;  // which cell of the anchor symbol
-      fbuf[(size_t)seg * fstride + (entry - size)] = sa.cand_exit[(size_t)seg * SEG_MAX_CAND + u];
+  for (unsigned w = w_first; w * PER < n_segs; w += w_step) {
+    const unsigned seg = w * PER + slot;
+    unsigned cls = 0, c = 0, k = 0, pred = 1;
+    bool want = false;
+    if (seg < n_segs) {
+      cls = sa.cls[seg];
+      if (seg_is_cand(cls)) {
+        c = seg_ctx_of<M>(seg_base, seg);
+        k = seg - seg_base[c];
+        pred = k ? (unsigned)sa.cls[seg - 1] : 1u;
+        want = k + 1 < seg_base[c + 1] - seg_base[c] && (!HEADS || seg_entry_known(k, pred));
+      }
+    }
+    unsigned long long todo = __ballot(want);
+    while (todo) {  // (uniform) one context at a time: usually one round
+      const unsigned cc = (unsigned)__shfl((int)c, __ffsll((long long)todo) - 1);
+      const bool mine = want && c == cc;
+      todo &= ~__ballot(mine);
+      fq_lds_wave_sync();  // the previous table is no longer read
+      const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[cc]);
+      if (!mine) continue;
+      const unsigned size = 1u << t.log;
+      const unsigned n = ctx_count[c], begin = k * S, end = min(n, begin + S);
+      const uint8_t *sym = sorted_sym + ctx_start[c];
+      const unsigned r = begin + sa.anchor[seg];
+      const unsigned s = sym[r] & (unsigned)(M::A - 1);
+      const int dfs = (int)t.tt[2 * s];
+      const unsigned n_cand = HEADS ? pred : cls;  // walks of this segment: sixteen per round
+      for (unsigned cand = j; cand < n_cand; cand += SEG_SLOT) {
+        if (!HEADS) {
+          unsigned x = t.state_table[dfs + (int)cls + (int)cand];
+          x = seg_state_range<M>(t, sym, r + 1, end, x);
+          sa.cand_exit[(size_t)seg * SEG_MAX_CAND + cand] = (uint16_t)x;
+        } else {
+          const unsigned entry = pred == 1 ? (unsigned)sa.entry_state[seg] : (unsigned)sa.cand_exit[(size_t)(seg - 1) * SEG_MAX_CAND + cand];
+          const unsigned x = seg_state_range<M>(t, sym, begin, r, entry);
+          const unsigned nb = (x + t.tt[2 * s + 1]) >> 16;
+          const unsigned u = (x >> nb) - cls;  // which cell of the anchor symbol
+          fbuf[(size_t)seg * fstride + (entry - size)] = sa.cand_exit[(size_t)seg * SEG_MAX_CAND + u];
+        }
+      }
     }
   }
+}
+
+// the walks up to the anchors (behind k_seg_stage1: they start from its results)
+template <class M>
+__global__ void __launch_bounds__(64)
+k_seg_heads(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
+            const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, unsigned S,
+            unsigned fstride, SegArrays sa, uint16_t *__restrict__ fbuf) {
+  extern __shared__ uint32_t lds[];
+  seg_cand_role<M, true>(lds, blockIdx.x, gridDim.x, sorted_sym, arrays, ct, ct_off, S, fstride, sa, fbuf);
 }
 
 // n classes (states in L.list) stepped through words [w0, w1) of the segment with the CTable
@@ -414,19 +420,26 @@ __device__ __forceinline__ void seg_sets_walk(SetsWaveLds &L, unsigned n, const 
   fq_lds_wave_sync();
 }
 
-// F of one opaque segment; one wave per workgroup, its own copy of the context's CTable
+// F of one segment that needs a full function (seg_wants_setfunc); one wave per workgroup, its own
+// copy of the context's CTable.  Workgroup = segment; the workgroups behind the last segment (pbase
+// on) build the power tables of the contexts that have uniform segments in this block.
 template <class M, unsigned PER0>
-__global__ void __launch_bounds__(64)
-k_seg_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays,
-              const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, unsigned S,
-              unsigned fstride, SegArrays sa, uint16_t *__restrict__ fbuf) {
-  extern __shared__ uint32_t lds[];
-  __shared__ SetsWaveLds L;
+__device__ __forceinline__ void seg_setfunc_role(uint32_t *lds, SetsWaveLds &L, unsigned idx, const uint8_t *__restrict__ sorted_sym,
+                                                 const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ ct,
+                                                 const uint32_t *__restrict__ ct_off, unsigned S, unsigned pbase, unsigned fstride,
+                                                 const SegArrays &sa, uint16_t *__restrict__ fbuf) {
   constexpr unsigned B = M::B;
-  if (blockIdx.x >= sa.counts[0]) return;  // the grid is an upper bound
   const uint32_t *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
-  const unsigned seg = sa.olist[blockIdx.x];
+  if (idx >= pbase) {  // (uniform)
+    const unsigned pc = idx - pbase;
+    const unsigned s = sa.usym[pc];
+    if (s != SEG_NONE) seg_pow_table<M, PER0>(lds, ct + ct_off[pc], s, S, fbuf + (size_t)(pbase + pc) * fstride);
+    return;
+  }
+  const unsigned seg = idx;
+  if (seg >= seg_base[B]) return;  // the grid is an upper bound
   const unsigned c = seg_ctx_of<M>(seg_base, seg), k = seg - seg_base[c];
+  if (!seg_wants_setfunc(sa, seg, k, seg_base[c + 1] - seg_base[c])) return;
   const LdsCTable t = stage_ctable<M>(lds, ct + ct_off[c]);
   const unsigned log = t.log, size = 1u << log, lane = fq_lane();
   const unsigned per = max(size >> 6, 1u), nw = max(size >> 5, 1u);
@@ -505,6 +518,26 @@ k_seg_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
   }
 }
 
+// Everything that needs the classes of k_seg_scan and nothing else, in ONE launch (a kernel boundary
+// on a lane's stream is a wait for room on a busy chip, and these are latency chains that fill a
+// fraction of it): workgroups [0, n_walk) are k_seg_walk<1>'s items, the next n_cand the candidate
+// walks behind the anchors, the rest k_seg_setfunc's segments and the contexts' power tables.
+template <class M, unsigned PER0>
+__global__ void __launch_bounds__(64)
+k_seg_stage1(const uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ out16, const uint32_t *__restrict__ arrays,
+             const uint32_t *__restrict__ ct, const uint32_t *__restrict__ ct_off, uint16_t *__restrict__ final_state,
+             unsigned S, unsigned n_walk, unsigned n_cand, unsigned pbase, unsigned fstride, SegArrays sa,
+             uint16_t *__restrict__ fbuf, StreamResult *res) {
+  extern __shared__ uint32_t lds[];
+  __shared__ SetsWaveLds L;
+  if (blockIdx.x < n_walk)
+    seg_walk_role<M, 1>(lds, blockIdx.x, sorted_sym, out16, arrays, ct, ct_off, final_state, S, sa, res);
+  else if (blockIdx.x < n_walk + n_cand)
+    seg_cand_role<M, false>(lds, blockIdx.x - n_walk, n_cand, sorted_sym, arrays, ct, ct_off, S, fstride, sa, fbuf);
+  else
+    seg_setfunc_role<M, PER0>(lds, L, blockIdx.x - n_walk - n_cand, sorted_sym, arrays, ct, ct_off, S, pbase, fstride, sa, fbuf);
+}
+
 // Entry states behind opaque segments.  Every other entry state is already there: k_seg_scan
 // stored the initial state of every chain, k_seg_walk<1> the state behind every transparent
 // segment.  A run of opaque segments is a chain x <- F_k[x] of dependent loads (0.5 us each;
@@ -524,7 +557,7 @@ struct ItemArrays {
 template <class M, unsigned PER0>
 __global__ void __launch_bounds__(64)
 k_seg_compose(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ logs,
-              const uint16_t *__restrict__ fbuf, unsigned fstride, SegArrays sa, ItemArrays ia) {
+              const uint16_t *__restrict__ fbuf, unsigned pbase, unsigned fstride, SegArrays sa, ItemArrays ia) {
   constexpr unsigned B = M::B;
   const uint32_t *seg_base = arrays + B + (B + 1), *item_base = seg_base + B + 1;
   const unsigned item = blockIdx.x, lane = fq_lane();
@@ -534,7 +567,7 @@ k_seg_compose(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ 
   const unsigned k0 = (item - item_base[c]) * 64, n_here = min(64u, nseg - k0);
   const unsigned seg0 = seg_base[c] + k0;
   // lane t looks at segment t of the item: function slot (SEG_NONE: transparent or last of the chain)
-  const unsigned slot = lane < n_here ? sa.fidx[seg0 + lane] : SEG_NONE;
+  const unsigned slot = lane < n_here ? seg_fslot(sa, seg0 + lane, k0 + lane, nseg, c, pbase) : SEG_NONE;
   const unsigned long long opaque = __ballot(slot != SEG_NONE);
   if (lane == 0) ia.has_g[item] = opaque != 0ull;
   if (!opaque) return;
@@ -590,7 +623,7 @@ k_seg_resolve2(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__
 template <class M>
 __global__ void __launch_bounds__(256)
 k_seg_resolve3(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__ logs,
-               const uint16_t *__restrict__ fbuf, unsigned fstride, SegArrays sa, ItemArrays ia) {
+               const uint16_t *__restrict__ fbuf, unsigned pbase, unsigned fstride, SegArrays sa, ItemArrays ia) {
   constexpr unsigned B = M::B;
   const uint32_t *seg_base = arrays + B + (B + 1), *item_base = seg_base + B + 1;
   const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
@@ -604,7 +637,7 @@ k_seg_resolve3(const uint32_t *__restrict__ arrays, const uint32_t *__restrict__
   for (unsigned t = 0; t < n_here; t++) {
     sa.entry_state[seg0 + t] = (uint16_t)x;
     if (k0 + t + 1 >= nseg) break;
-    const unsigned sl = sa.fidx[seg0 + t];
+    const unsigned sl = seg_fslot(sa, seg0 + t, k0 + t, nseg, c, pbase);
     x = sl == SEG_NONE ? (unsigned)sa.entry_state[seg0 + t + 1] : (unsigned)fbuf[(size_t)sl * fstride + (x - size)];
   }
   if (k0 + n_here < nseg) sa.entry_state[seg0 + n_here] = (uint16_t)x;  // first segment of the next item

@@ -446,9 +446,9 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
 // x <- F_last[x] runs from group to group.  A chain of more than SEQ_ITEM_GROUPS groups (one context
 // holding most of a block: 3 600 groups for 256 MiB of poly-A) is resolved in three levels over
 // ITEMS of 64 groups, like the quality stream's runs of opaque segments:
-//  k_seq_compose  one wave per item: the item's composed function for every possible entry state
-//  k_seq_resolve  one thread per context: short chain: group by group; long chain: item by item
-//  k_seq_expand   one thread per item of a long chain: group by group inside the item
+//  compose  one wave per item: the item's composed function for every possible entry state
+//  resolve  one thread per context: item by item
+//  expand   one thread per item: group by group inside the item
 __device__ __forceinline__ unsigned seq_resolve_groups(const uint32_t *__restrict__ fseg, const uint32_t *__restrict__ seg,
                                                        const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned c, unsigned Q,
                                                        unsigned nf, unsigned ns, unsigned s_begin, unsigned s_end, unsigned xo,
@@ -471,14 +471,16 @@ __device__ __forceinline__ unsigned seq_resolve_groups(const uint32_t *__restric
   return xo;
 }
 
+constexpr unsigned SEQ_RESOLVE_THREADS = 1024;
+
+// the composed function of one item (64 groups) for every possible entry state; one wave
 template <unsigned PER0>
-__global__ void __launch_bounds__(64)
-k_seq_compose(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs, const uint16_t *__restrict__ fbuf,
-              unsigned fstride, unsigned qmax, unsigned gmin, uint16_t *__restrict__ cbuf) {
+__device__ __forceinline__ void seq_compose_item(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs,
+                                                 const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned qmax, unsigned gmin,
+                                                 unsigned item, uint16_t *__restrict__ cbuf) {
   constexpr unsigned B = SeqModel::B;
   const uint32_t *fseg = plan + (B + 1), *citem = plan + 4 * (B + 1);
-  const unsigned item = blockIdx.x, lane = fq_lane();
-  if (item >= citem[B]) return;  // the grid is an upper bound
+  const unsigned lane = fq_lane();
   const unsigned c = seq_item_ctx(citem, item);
   const unsigned nf = fseg[c + 1] - fseg[c], Q = seq_group_of(nf, qmax, gmin), nl = (nf + Q - 1) / Q;
   const unsigned g0 = (item - citem[c]) * SEQ_ITEM_GROUPS, g1 = min(g0 + SEQ_ITEM_GROUPS, nl);
@@ -501,36 +503,45 @@ k_seq_compose(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ lo
   }
 }
 
-__global__ void __launch_bounds__(256)
-k_seq_resolve(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned qmax,
-              unsigned gmin, const uint16_t *__restrict__ cbuf, uint16_t *__restrict__ item_entry, uint16_t *__restrict__ entry) {
+// One workgroup, one launch (every kernel boundary on a lane's stream is a wait for the chip to have
+// room again): thread c resolves a short chain group by group; long chains go through the three
+// levels, the levels separated by workgroup barriers.
+template <unsigned PER0>
+__global__ void __launch_bounds__(SEQ_RESOLVE_THREADS)
+k_seq_resolve(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs, const uint16_t *__restrict__ fbuf,
+              unsigned fstride, unsigned qmax, unsigned gmin, uint16_t *__restrict__ cbuf, uint16_t *__restrict__ item_entry,
+              uint16_t *__restrict__ entry) {
   constexpr unsigned B = SeqModel::B;
   const uint32_t *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *citem = plan + 4 * (B + 1);
   const unsigned c = threadIdx.x;
-  const unsigned ns = seg[c + 1] - seg[c], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin);
-  const unsigned ni = citem[c + 1] - citem[c];
-  unsigned xo = 0;  // FSE_initCState: state = size
-  if (ni == 0) {
-    (void)seq_resolve_groups(fseg, seg, fbuf, fstride, c, Q, nf, ns, 0, ns, xo, entry);
-  } else {
+  unsigned ns = 0, nf = 0, Q = 1, ni = 0;
+  if (c < B) {
+    ns = seg[c + 1] - seg[c]; nf = ns ? ns - 1 : 0; Q = seq_group_of(nf, qmax, gmin);
+    ni = citem[c + 1] - citem[c];
+    if (ni == 0) (void)seq_resolve_groups(fseg, seg, fbuf, fstride, c, Q, nf, ns, 0, ns, 0u, entry);  // FSE_initCState: state = size
+  }
+  const unsigned n_items = citem[B];
+  if (n_items == 0) return;  // (uniform) no long chain in this block
+  for (unsigned item = threadIdx.x >> 6; item < n_items; item += SEQ_RESOLVE_THREADS / 64)
+    seq_compose_item<PER0>(plan, logs, fbuf, fstride, qmax, gmin, item, cbuf);
+  __threadfence();
+  __syncthreads();
+  if (c < B && ni) {
+    unsigned xo = 0;
     for (unsigned i = 0; i < ni; i++) {
       item_entry[citem[c] + i] = (uint16_t)xo;
-      if (i + 1 < ni) xo = cbuf[(size_t)(citem[c] + i) * fstride + (xo >> 1)];
+      if (i + 1 < ni) xo = __hip_atomic_load(&cbuf[(size_t)(citem[c] + i) * fstride + (xo >> 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-}
-
-__global__ void __launch_bounds__(64)
-k_seq_expand(const uint32_t *__restrict__ plan, const uint16_t *__restrict__ fbuf, unsigned fstride, unsigned qmax,
-             unsigned gmin, const uint16_t *__restrict__ item_entry, uint16_t *__restrict__ entry) {
-  constexpr unsigned B = SeqModel::B;
-  const uint32_t *fseg = plan + (B + 1), *seg = plan + 2 * (B + 1), *citem = plan + 4 * (B + 1);
-  const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= citem[B]) return;  // the grid is an upper bound
-  const unsigned c = seq_item_ctx(citem, item);
-  const unsigned ns = seg[c + 1] - seg[c], nf = ns ? ns - 1 : 0, Q = seq_group_of(nf, qmax, gmin);
-  const unsigned s_begin = (item - citem[c]) * SEQ_ITEM_GROUPS * Q, s_end = min(s_begin + SEQ_ITEM_GROUPS * Q, ns);
-  (void)seq_resolve_groups(fseg, seg, fbuf, fstride, c, Q, nf, ns, s_begin, s_end, item_entry[item], entry);
+  __threadfence();
+  __syncthreads();
+  for (unsigned item = threadIdx.x; item < n_items; item += SEQ_RESOLVE_THREADS) {
+    const unsigned ic = seq_item_ctx(citem, item);
+    const unsigned ins = seg[ic + 1] - seg[ic], inf = ins ? ins - 1 : 0, iQ = seq_group_of(inf, qmax, gmin);
+    const unsigned s_begin = (item - citem[ic]) * SEQ_ITEM_GROUPS * iQ, s_end = min(s_begin + SEQ_ITEM_GROUPS * iQ, ins);
+    const unsigned xo = __hip_atomic_load(&item_entry[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)seq_resolve_groups(fseg, seg, fbuf, fstride, ic, iQ, inf, ins, s_begin, s_end, xo, entry);
+  }
 }
 
 // Step C: one lane per segment, 64 segments of one context per wave

@@ -399,7 +399,9 @@ k_group_prefix(uint32_t *__restrict__ group_sum, unsigned n_groups, unsigned B, 
 // run, segment and work-item prefix sums.
 // arrays: ctx_count[B] | ctx_start[B+1] | seg_base[B+1] | item_base[B+1]
 __global__ void __launch_bounds__(1024)
-k_ctx_layout(unsigned B, unsigned S, uint32_t *__restrict__ arrays) {
+k_ctx_layout(unsigned B, unsigned S, uint32_t *__restrict__ arrays, uint32_t *__restrict__ fill_none) {
+  if (fill_none)  // SegArrays::usym of the generic chain kernels starts from "none" (one memset less on the stream)
+    for (unsigned c = threadIdx.x; c < B; c += blockDim.x) fill_none[c] = 0xFFFFFFFFu;
   __shared__ unsigned part[3][1024];
   uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1,
            *item_base = seg_base + B + 1;

@@ -203,7 +203,7 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
       const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j % NBUF]);
       uint16_t *gpos = lpos16 + e0 + j * TS_BATCH;
       const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
-      constexpr unsigned G = 8;
+      constexpr unsigned G = 4;  // (four iterations in flight: eight cost 22 more VGPRs for the whole kernel, which every tile pays)
       for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // wave-uniform trip count, branch-free, as below
         unsigned key[G], pos[G], sy[G], head_of[G];
 #pragma unroll
@@ -485,11 +485,11 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
       acc |= (unsigned long long)(v[i] & 0xFFFu) << nacc;
       nacc += nb;
       if (nacc >= 32) {
-        atomicOr(&words[w], (uint32_t)acc);
-        acc >>= 32; nacc -= 32; w++;
+        if ((uint32_t)acc) atomicOr(&words[w], (uint32_t)acc);  // (OR-ing nothing is left out: on data that codes in a fraction of a bit per
+        acc >>= 32; nacc -= 32; w++;                            //  symbol all threads of a wave would meet on one word)
       }
     }
-    if (nacc) atomicOr(&words[w], (uint32_t)acc);
+    if ((uint32_t)acc) atomicOr(&words[w], (uint32_t)acc);
     __syncthreads();
     if (b1 != b0) {
       const unsigned long long gw0 = b0 >> 5;

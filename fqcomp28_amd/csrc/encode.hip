@@ -170,8 +170,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   // segment tables of the generic chain kernels (SegArrays, then ItemArrays), every array 16-byte aligned
   auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   const size_t gs = gen_max_segs;
-  const size_t sa_anchor = 0, sa_fidx = al16(sa_anchor + gs * 4), sa_olist = al16(sa_fidx + gs * 4), sa_tlist = al16(sa_olist + gs * 4),
-               sa_hlist = al16(sa_tlist + gs * 16), sa_counts = al16(sa_hlist + gs * 16), sa_usym = sa_counts + 16,
+  const size_t sa_anchor = 0, sa_usym = al16(sa_anchor + gs * 4),
                sa_entry = al16(sa_usym + (size_t)B * 4), sa_cand = al16(sa_entry + gs * 2), sa_cls = al16(sa_cand + gs * SEG_MAX_CAND * 2),
                ia_has_g = al16(sa_cls + gs), ia_entry = al16(ia_has_g + (size_t)max_items * 4), ia_g = al16(ia_entry + (size_t)max_items * 2),
                seg_arrays_bytes = ia_g + (size_t)max_items * gen_fstride * 2 + 64;
@@ -217,7 +216,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if (!dbg_off) hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
   if (!dbg_off) hipLaunchKernelGGL(k_group_prefix, dim3((B + 255) / 256), dim3(256), 0, st, sc.group_sum.as<uint32_t>(), n_groups, B, arrays);
-  if (!dbg_off) hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, B, S, arrays);
+  if (!dbg_off) hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, B, S, arrays,
+                     serial_seq ? nullptr : reinterpret_cast<uint32_t *>(sc.seg_arrays.as<uint8_t>() + sa_usym));
   if (!dbg_off) hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B,
                      sc.tile_base.as<uint32_t>());
@@ -287,11 +287,9 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
       FQ_SPAN_BEGIN("seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
       if (!dbg_off) {
         if (tab.max_log <= 11)
-          hipLaunchKernelGGL(k_seq_compose<32>, dim3(max_citems), dim3(64), 0, st, plan, tab.logs, fbuf, seq_fstride, Q, gmin, cbuf);
+          hipLaunchKernelGGL(k_seq_resolve<32>, dim3(1), dim3(SEQ_RESOLVE_THREADS), 0, st, plan, tab.logs, fbuf, seq_fstride, Q, gmin, cbuf, item_entry, entry);
         else
-          hipLaunchKernelGGL(k_seq_compose<64>, dim3(max_citems), dim3(64), 0, st, plan, tab.logs, fbuf, seq_fstride, Q, gmin, cbuf);
-        hipLaunchKernelGGL(k_seq_resolve, dim3(1), dim3(256), 0, st, plan, fbuf, seq_fstride, Q, gmin, cbuf, item_entry, entry);
-        hipLaunchKernelGGL(k_seq_expand, dim3((max_citems + 63) / 64), dim3(64), 0, st, plan, fbuf, seq_fstride, Q, gmin, item_entry, entry);
+          hipLaunchKernelGGL(k_seq_resolve<64>, dim3(1), dim3(SEQ_RESOLVE_THREADS), 0, st, plan, tab.logs, fbuf, seq_fstride, Q, gmin, cbuf, item_entry, entry);
       }
       FQ_SPAN_END();
       FQ_SPAN_BEGIN("seq.chains");  dbg_off = (dbg_mask & 8u) != 0;
@@ -303,44 +301,28 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     uint8_t *sab = sc.seg_arrays.as<uint8_t>();
     SegArrays sa;
     sa.anchor = reinterpret_cast<uint32_t *>(sab + sa_anchor);
-    sa.fidx = reinterpret_cast<uint32_t *>(sab + sa_fidx);
-    sa.olist = reinterpret_cast<uint32_t *>(sab + sa_olist);
-    sa.tlist = reinterpret_cast<uint32_t *>(sab + sa_tlist);
-    sa.hlist = reinterpret_cast<uint32_t *>(sab + sa_hlist);
-    sa.counts = reinterpret_cast<uint32_t *>(sab + sa_counts);
     sa.usym = reinterpret_cast<uint32_t *>(sab + sa_usym);
     sa.entry_state = reinterpret_cast<uint16_t *>(sab + sa_entry);
     sa.cand_exit = reinterpret_cast<uint16_t *>(sab + sa_cand);
     sa.cls = sab + sa_cls;
     uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
-    const unsigned cand_lds = (64 / SEG_SLOT) * lds_ct, cand_grid = min(gen_max_segs / (64 / SEG_SLOT) + 1, 8u * ctx->n_cus);
-    FQ_HIP(hipMemsetAsync(sa.counts, 0, 16, st));
-    FQ_HIP(hipMemsetAsync(sa.usym, 0xFF, (size_t)B * 4, st));
+    const unsigned cand_grid = min(gen_max_segs / (64 / SEG_SLOT) + 1, 32u * ctx->n_cus);
     if (!dbg_off) hipLaunchKernelGGL(k_seg_scan<M>, dim3((gen_max_segs + 3) / 4), dim3(256), 0, st, sc.sorted_sym.as<uint8_t>(),
                        arrays, tab.reset_mask, tab.norm, tab.logs, S, sa);
-    if (!dbg_off) hipLaunchKernelGGL(k_seg_plan<M>, dim3((gen_max_segs + 255) / 256), dim3(256), 0, st, arrays, gen_pbase, sa);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk1" : "seq.walk1");  dbg_off = (dbg_mask & 8u) != 0;
-    if (!dbg_off) hipLaunchKernelGGL((k_seg_walk<M, 1>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
-                       sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, sa, res);
-    FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.setfunc" : "seq.setfunc");  dbg_off = (dbg_mask & 8u) != 0;
-    if (!dbg_off) hipLaunchKernelGGL(k_seg_pow<M>, dim3(B), dim3(256), 0, st, tab.ct, tab.ct_off, S, gen_pbase, gen_fstride, sa, fbuf);
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.stage1" : "seq.stage1");  dbg_off = (dbg_mask & 8u) != 0;
     if (dbg_off) {
     } else if (tab.max_log <= 11)
-      hipLaunchKernelGGL((k_seg_setfunc<M, 32>), dim3(n_sym / S + 1), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
-                         arrays, tab.ct, tab.ct_off, S, gen_fstride, sa, fbuf);
+      hipLaunchKernelGGL((k_seg_stage1<M, 32>), dim3(max_items + cand_grid + gen_pbase + B), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                         sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, max_items, cand_grid, gen_pbase, gen_fstride, sa, fbuf, res);
     else
-      hipLaunchKernelGGL((k_seg_setfunc<M, 64>), dim3(n_sym / S + 1), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
-                         arrays, tab.ct, tab.ct_off, S, gen_fstride, sa, fbuf);
+      hipLaunchKernelGGL((k_seg_stage1<M, 64>), dim3(max_items + cand_grid + gen_pbase + B), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
+                         sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, max_items, cand_grid, gen_pbase, gen_fstride, sa, fbuf, res);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.cand" : "seq.cand");  dbg_off = (dbg_mask & 8u) != 0;
-    if (!dbg_off) {
-      hipLaunchKernelGGL((k_seg_cand<M, false>), dim3(cand_grid), dim3(64), cand_lds, st, sc.sorted_sym.as<uint8_t>(), arrays, tab.ct,
-                         tab.ct_off, S, lds_ct / 4, gen_fstride, sa, fbuf);
-      hipLaunchKernelGGL((k_seg_cand<M, true>), dim3(cand_grid), dim3(64), cand_lds, st, sc.sorted_sym.as<uint8_t>(), arrays, tab.ct,
-                         tab.ct_off, S, lds_ct / 4, gen_fstride, sa, fbuf);
-    }
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.heads" : "seq.heads");  dbg_off = (dbg_mask & 8u) != 0;
+    if (!dbg_off)
+      hipLaunchKernelGGL(k_seg_heads<M>, dim3(cand_grid), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(), arrays, tab.ct,
+                         tab.ct_off, S, gen_fstride, sa, fbuf);
     FQ_SPAN_END();
     FQ_SPAN_BEGIN(M::STREAM ? "qual.resolve" : "seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
     if (!dbg_off) {
@@ -349,12 +331,12 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
       ia.item_entry = reinterpret_cast<uint16_t *>(sab + ia_entry);
       ia.g = reinterpret_cast<uint16_t *>(sab + ia_g);
       if (tab.max_log <= 11)
-        hipLaunchKernelGGL((k_seg_compose<M, 32>), dim3(max_items), dim3(64), 0, st, arrays, tab.logs, fbuf, gen_fstride, sa, ia);
+        hipLaunchKernelGGL((k_seg_compose<M, 32>), dim3(max_items), dim3(64), 0, st, arrays, tab.logs, fbuf, gen_pbase, gen_fstride, sa, ia);
       else
-        hipLaunchKernelGGL((k_seg_compose<M, 64>), dim3(max_items), dim3(64), 0, st, arrays, tab.logs, fbuf, gen_fstride, sa, ia);
+        hipLaunchKernelGGL((k_seg_compose<M, 64>), dim3(max_items), dim3(64), 0, st, arrays, tab.logs, fbuf, gen_pbase, gen_fstride, sa, ia);
       hipLaunchKernelGGL(k_seg_resolve2<M>, dim3((B + 255) / 256), dim3(256), 0, st, arrays, tab.logs, gen_fstride, sa, ia);
       hipLaunchKernelGGL(k_seg_resolve3<M>, dim3((max_items + 255) / 256), dim3(256), 0, st, arrays, tab.logs, fbuf,
-                         gen_fstride, sa, ia);
+                         gen_pbase, gen_fstride, sa, ia);
     }
     FQ_SPAN_END();
     FQ_SPAN_BEGIN(M::STREAM ? "qual.walk2" : "seq.walk2");  dbg_off = (dbg_mask & 8u) != 0;

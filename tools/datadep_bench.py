@@ -6,7 +6,7 @@ encode GB/s and decode ns per symbol of 4 x 64 MiB blocks for
                 context, no reset symbols: what current Illumina output looks like to this model)
   constant   -- every quality 'F', every base 'A' (one context per stream from the fourth symbol on)
 Every run is a round trip (decode output compared byte for byte).  One JSON line per data kind.
-    python tools/datadep_bench.py [block MiB] [segment of the quality chain kernels, 0 = default]
+    python tools/datadep_bench.py [block MiB] [segment of the quality chain kernels, 0 = default] [kinds, comma separated]
 (binned data with segments of 4096 / 8192 / 16384: 41.1 / 42.5 / 38.1 GB/s: the segment length is not the lever.)"""
 import json
 import os
@@ -50,8 +50,9 @@ def remake(blocks, kind, seed=11):
 def main():
     mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     seg = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # segment of the quality chain kernels (0 = default)
+    kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ("synthetic", "binned", "constant")
     base = bench.make_workload(F, 4 * mib << 20, mib << 20, seed=28)
-    for kind in ("synthetic", "binned", "constant"):
+    for kind in kinds:
         blocks = remake(base, kind)
         sft, qft = bench.sample_tables(F, blocks, max(32, mib // 2) << 20, 0)
         ctx = F.Context(sft, qft, device=0)
