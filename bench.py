@@ -33,6 +33,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 8 blocks in flight x (
 import numpy as np  # noqa: E402
 
 MB = 1e6
+PROFILE_TRAFFIC = "r03_traffic.json"  # counters and rocprof launch times of this round (tools/refresh_profiles.py)
 
 
 def kernel_sources_sha():
@@ -46,12 +47,13 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def make_workload(F, total_bytes, block_bytes, seed, first_id=0):
-    """-> list of (raw, recs) blocks of whole records, about block_bytes each."""
+def make_workload(F, total_bytes, block_bytes, seed, first_id=0, mode=2):
+    """-> list of (raw, recs) blocks of whole records, about block_bytes each (mode: include/fqgpu.h,
+    fqgpu_synth_fastq: 2 = BASELINE configs[1], 4 = configs[3], 3 = binned qualities, 5 = constant)."""
     blocks, done, next_id = [], 0, first_id
     while done < total_bytes:
         want = min(block_bytes, total_bytes - done)
-        raw, n = F.synth_fastq(want, 2, seed=seed, first_read_id=next_id)
+        raw, n = F.synth_fastq(want, mode, seed=seed, first_read_id=next_id)
         if n == 0:
             break
         next_id += n
@@ -78,6 +80,64 @@ def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     return O
+
+
+def other_data(F, O, device, lanes, steps, kind, mode, total_mib, block_mib, sample_mib, decode_mib):
+    """The same measurement on data that is NOT the headline config (after the timed region, rank 0):
+    encode MB/s of `total_mib` in `block_mib` blocks with `lanes` blocks in flight, one WHOLE block
+    byte-compared with the oracle, and the decode walk's ns per symbol on 4 x `decode_mib` MiB of it."""
+    blocks = make_workload(F, total_mib << 20, block_mib << 20, seed=28, mode=mode)
+    sft, qft = sample_tables(F, blocks, sample_mib << 20, device)
+    ctx = F.Context(sft, qft, device=device)
+    ctx.set_lanes(lanes)
+    db = [ctx.dblock(raw, recs) for raw, recs in blocks]
+    for b in db:
+        b.encode()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for b in db:
+            b.encode()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    raw_bytes = sum(r.size for r, _ in blocks)
+    out = {"data": kind, "blocks": "%d x %d MiB" % (len(blocks), block_mib), "steps": steps,
+           "MBps": round(raw_bytes * steps / dt / MB, 1), "ms_per_step": round(dt / steps * 1e3, 3)}
+    sizes = [b.status() for b in db]
+    out["rc"] = [rc for rc, _ in sizes]
+    out["seq_bytes"] = int(sum(st["seq_len"] for _, st in sizes))
+    out["qual_bytes"] = int(sum(st["qual_len"] for _, st in sizes))
+    if O is not None:  # a whole block of the last timed step against the oracle, every stream byte for byte
+        octx = O.OracleCtx(sft, qft)
+        e = octx.encode(*blocks[-1])
+        g = db[-1].fetch()
+        out["oracle_block_all_equal"] = bool(e["rc"] == 0 and all(np.array_equal(g[k], e[k]) for k in ("seq", "qual", "readlens", "n_count", "n_pos")))
+        out["oracle_block_raw_bytes"] = int(blocks[-1][0].size)
+        octx.close()
+    for b in db:
+        b.close()
+    if decode_mib:  # the serial walk per (block, stream): 4 blocks = 8 chains side by side
+        small = make_workload(F, 4 * decode_mib << 20, decode_mib << 20, seed=29, mode=mode)
+        sdb = [ctx.dblock(raw, recs) for raw, recs in small]
+        for b in sdb:
+            b.encode()
+        ctx.sync()
+        ok = all(b.status()[0] == 0 for b in sdb)
+        for b in sdb:
+            b.wipe()
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.decode_dblocks(sdb)
+        ctx.sync()
+        dd = time.perf_counter() - t0
+        ok = ok and all(b.status()[0] == 0 for b in sdb) and all(np.array_equal(b.fetch_raw(), r) for b, (r, _) in zip(sdb, small))
+        out["decode_ns_per_symbol_per_lane"] = round(dd * 1e9 / max(int(r["len"].sum()) for _, r in small), 1)
+        out["decode_blocks"] = "4 x %d MiB" % decode_mib
+        out["decode_roundtrip_ok"] = bool(ok)
+        for b in sdb:
+            b.close()
+    ctx.close()
+    return out
 
 
 def cpu_baseline(blocks, sft, qft, seconds_budget=24.0):
@@ -142,6 +202,7 @@ def main():
     ap.add_argument("--skip-decode", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-host", action="store_true")
+    ap.add_argument("--skip-other-data", action="store_true", help="no binned / constant / configs[3] runs after the timed region")
     args = ap.parse_args()
 
     from fqcomp28_amd import farm
@@ -269,9 +330,9 @@ def main():
     # the device code is the code it was measured on; otherwise null.
     traffic, traffic_src, rocprof_avg_ms = None, None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)) as fh:
             tj = json.load(fh)
-        traffic_src = {"file": "profiles/r02_traffic.json", "commit": tj.get("commit"), "kernel_sources_sha": tj.get("kernel_sources_sha"),
+        traffic_src = {"file": "profiles/" + PROFILE_TRAFFIC, "commit": tj.get("commit"), "kernel_sources_sha": tj.get("kernel_sources_sha"),
                        "current_kernel_sources_sha": kernel_sources_sha()}
         if tj.get("kernel_sources_sha") == traffic_src["current_kernel_sources_sha"] and block_mib == tj.get("block_mib", 256):
             k = tj.get("kernels", {}).get(dom[0])
@@ -281,10 +342,20 @@ def main():
             traffic_src["block_traffic_bytes"] = tj.get("block_traffic_bytes")
     except Exception:
         pass
+    # One figure per key: `achieved` / `frac` divide by the kernel's own duration -- the rocprofv3 launch
+    # time of the committed profile while the device code is the code it was taken on, else (null
+    # profile) the HIP-event span measured here; the span (which also holds the wait for room on a chip
+    # busy with the other lanes' kernels) is always given beside it as frac_event_span.
+    span_achieved = achieved
+    if rocprof_avg_ms:
+        achieved = alg_dom / (rocprof_avg_ms / 1e3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_from_committed_profile": traffic_src,
-                "rocprof_avg_launch_ms_from_committed_profile": rocprof_avg_ms,
-                "avg_launch_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(alg_dom),
+                "frac": round(achieved / 8000.0, 5), "frac_from": "rocprofv3 launch time of the committed profile (same device code)" if rocprof_avg_ms
+                else "HIP-event span of this run (no committed profile of this device code)",
+                "frac_event_span": round(span_achieved / 8000.0, 5), "achieved_event_span": round(span_achieved, 2),
+                "traffic": traffic, "traffic_from_committed_profile": traffic_src,
+                "rocprof_avg_launch_ms": rocprof_avg_ms,
+                "event_span_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(alg_dom),
                 "launches_timed": calls.get(dom[0], 0),
                 "job_GBps": round(alg_block * len(blocks) * args.steps / elapsed / 1e9, 2),
                 "job_frac": round(alg_block * len(blocks) * args.steps / elapsed / 1e9 / 8000.0, 5),
@@ -437,11 +508,18 @@ def main():
             d1 = time.perf_counter() - t0
             assert got[0] == 0
             best = d1 if best is None else min(best, d1)
-        # a host-pointer result against the resident path's: same bytes
-        same_hp = bool(check is None or (pins[(len(blocks) - 1) % T][0].size == blocks[-1][0].size))
+        # a host-pointer result of the T-thread run against the resident path's streams of the same block, byte for byte
+        t_chk = 0
+        hp_bufs = pins[t_chk][2]
+        ref_b = ctx.dblock(*blocks[t_chk % len(blocks)])
+        ref_b.encode()
+        ref = ref_b.fetch()
+        ref_b.close()
+        same_hp = bool(all(np.array_equal(np.asarray(hp_bufs[k])[: len(ref[k])], ref[k]) for k in ("seq", "qual", "readlens", "n_count")))
         extra["host_pointer"] = {"threads": T, "handles": T, "blocks_coded": T * per_thread, "buffers": "block and streams page-locked (fqgpu_host_alloc), side buffers pageable",
                                  "includes": "H2D of the block + record table, encode, D2H of both streams and the side streams",
-                                 "one_thread_pageable_MBps": round(raw0.size / best / MB, 1), "sane": same_hp}
+                                 "one_thread_pageable_MBps": round(raw0.size / best / MB, 1),
+                                 "streams_equal_resident_path": same_hp}
         for c in ctxs[1:]:
             c.close()
         t0 = time.perf_counter()
@@ -455,6 +533,18 @@ def main():
         pb.close()
         extra["parser"] = {"host_parse_MBps": round(raw0.size / t_host / MB, 1),
                            "gpu_create_from_raw_MBps_incl_h2d": round(raw0.size / t_gpu / MB, 1), "tables_equal": ok}
+
+    # ---- data that is not the headline config (rank 0, after the timed region; not part of `value`)
+    if rank == 0 and not args.skip_other_data:
+        Oc = None if args.skip_cpu else _oracle()
+        lanes = max(1, min(args.lanes, 8))
+        od = [other_data(F, Oc, device, lanes, 5, "binned qualities: four levels at 5/10/15/70 %, kept w.p. 0.85 (synth mode 3)", 3, 1024, 256, 128, 16),
+              other_data(F, Oc, device, lanes, 5, "constant: every base A, every quality F (synth mode 5)", 5, 1024, 256, 128, 16),
+              other_data(F, Oc, device, lanes, 5, "BASELINE configs[3]: 256 MiB, length U[50,300], 1 % N (synth mode 4), in -R 64 blocks", 4, 256, 64, 128, 0)]
+        extra["encode_binned_MBps"], extra["encode_constant_MBps"], extra["encode_config4_MBps"] = (o["MBps"] for o in od)
+        extra["decode_binned_ns_per_symbol"] = od[0].get("decode_ns_per_symbol_per_lane")
+        extra["decode_constant_ns_per_symbol"] = od[1].get("decode_ns_per_symbol_per_lane")
+        extra["other_data"] = od
 
     cpu = cpu_dec = None
     if rank == 0 and not args.skip_cpu:

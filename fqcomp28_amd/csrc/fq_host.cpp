@@ -95,6 +95,21 @@ extern "C" size_t fqgpu_synth_fastq(uint8_t *dst, size_t cap, int mode, uint64_t
     if (mode == 1) {
       memset(q, 'I', L);
       for (unsigned i = 0; i < L; i++) if (g.next() % 1000 == 0) s[i] = 'N';
+    } else if (mode == 3) {  // binned: four levels at 5/10/15/70 %, the level of the previous position kept with p = 0.85
+      static const char LEVELS[4] = {'#', '-', '8', 'F'};
+      unsigned level = 3;
+      uint64_t r = 0;
+      for (unsigned i = 0; i < L; i++) {
+        if ((i & 1u) == 0) r = g.next();
+        const unsigned keep = (unsigned)(r & 0xFFFF), pick = (unsigned)((r >> 16) & 0xFFFF);
+        r >>= 32;
+        if (i == 0 || keep >= 55705u)  // 0.85 * 65536
+          level = pick < 3277u ? 0u : pick < 9830u ? 1u : pick < 19661u ? 2u : 3u;
+        q[i] = (uint8_t)LEVELS[level];
+      }
+    } else if (mode == 5) {  // constant: one base, one quality (one context per stream from the fourth symbol on)
+      memset(s, 'A', L);
+      memset(q, 'F', L);
     } else {
       for (unsigned i = 0; i < L; i++) q[i] = (uint8_t)(33 + phred_normal(g));
       if (mode == 4)

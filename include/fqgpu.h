@@ -218,7 +218,11 @@ long fqgpu_parse_fastq(const uint8_t *raw, size_t len, fqgpu_rec *recs, size_t c
 /* Deterministic synthetic FASTQ for the BASELINE.json configs:
  * mode 1: 150 bp, N w.p. 0.001, all quals 'I'; mode 2: 150 bp uniform ACGT,
  * Phred ~ round(N(34,5)) clipped to [2,41]; mode 4: length U[50,300], N w.p. 0.01
- * with quality '#'.  Writes whole records only; returns bytes written. */
+ * with quality '#'.  Two more modes are NOT BASELINE configs; they probe how the path depends on
+ * the data (bench.py: encode_binned_MBps, encode_constant_MBps): mode 3: mode 2's bases with binned
+ * qualities -- '#', '-', '8', 'F' at 5/10/15/70 %, the previous position's level kept w.p. 0.85 (no
+ * symbol with a single table cell, long runs of one context); mode 5: every base 'A', every quality
+ * 'F' (one context per stream).  Writes whole records only; returns bytes written. */
 size_t fqgpu_synth_fastq(uint8_t *dst, size_t cap, int mode, uint64_t seed, uint64_t first_read_id,
                          uint64_t *n_reads_out);
 
