@@ -71,6 +71,13 @@ _PROTOS = {
                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_size_t), C.c_uint]),
+    "fqgpu_encode_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint,
+                                     C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "fqgpu_encode_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fqgpu_encode_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "fqgpu_encode_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                   C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.POINTER(C.c_size_t)]),
     "fqgpu_decode_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.c_size_t]),
@@ -400,6 +407,32 @@ class Context:
         rc, sl, ql, nn = self.encode_block_into(raw, recs, bufs, flags)
         return dict(rc=rc, seq=bufs["seq"][:sl].copy(), qual=bufs["qual"][:ql].copy(), readlens=bufs["readlens"],
                     n_count=bufs["n_count"], n_pos=bufs["n_pos"][:nn].copy(), raw_after=raw)
+
+    def encode_raw(self, raw, flags=0, recs=None):
+        """The two-halves call on an UNPARSED chunk (fqgpu_encode_begin / _records / _wait / _end): the
+        record table comes back from the GPU.  -> dict like encode_block's, plus recs and used_len."""
+        raw = np.array(raw, dtype=np.uint8, copy=True)
+        n, nb, used = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        if recs is not None:
+            recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+        rc = lib().fqgpu_encode_begin(self.h, _p(raw), raw.size, _p(recs) if recs is not None else None,
+                                      0 if recs is None else len(recs), flags, C.byref(n), C.byref(nb), C.byref(used))
+        if rc:
+            return dict(rc=rc)
+        table = np.zeros(n.value, dtype=REC_DTYPE)
+        rc = lib().fqgpu_encode_records(self.h, _p(table), len(table))
+        if rc:
+            return dict(rc=rc)
+        sl, ql, nn = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        rc = lib().fqgpu_encode_wait(self.h, C.byref(sl), C.byref(ql), C.byref(nn))
+        if rc:
+            return dict(rc=rc)
+        seq, qual = np.zeros(sl.value, np.uint8), np.zeros(ql.value, np.uint8)
+        readlens, n_count, n_pos = np.zeros(n.value, np.uint16), np.zeros(n.value, np.uint16), np.zeros(nn.value, np.uint16)
+        rc = lib().fqgpu_encode_end(self.h, _p(raw), _p(seq), seq.size, C.byref(sl), _p(qual), qual.size, C.byref(ql),
+                                    _p(readlens), _p(n_count), _p(n_pos), n_pos.size, C.byref(nn))
+        return dict(rc=rc, seq=seq, qual=qual, readlens=readlens, n_count=n_count, n_pos=n_pos, raw_after=raw,
+                    recs=table, used_len=used.value, n_bases=nb.value)
 
     def decode_block(self, seq, qual, n_count, n_pos, recs, raw_skeleton):
         out = np.array(raw_skeleton, dtype=np.uint8, copy=True)

@@ -128,7 +128,8 @@ extern "C" void *fqgpu_host_alloc(size_t bytes) {
     if (!p) {
       int n = 0;
       const bool gpu = hipGetDeviceCount(&n) == hipSuccess && n > 0;
-      pinned = gpu && hipHostMalloc(&p, total, hipHostMallocDefault) == hipSuccess;
+      // Portable: the cache is process-wide, a block pinned while one device was current may be handed to a worker of another
+      pinned = gpu && hipHostMalloc(&p, total, hipHostMallocPortable) == hipSuccess;
       if (!pinned) { (void)hipGetLastError(); p = nullptr; }
     }
   }
@@ -926,6 +927,151 @@ static int hp_block_acquire(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_
   return FQGPU_OK;
 }
 
+// Waits for everything the handle has queued before an error return: the caller's buffers (page-locked
+// vectors that go back to the pin cache, where another thread may pick them up) must not be read or
+// written by a copy that is still in flight.
+static int hp_fail(fqgpu_ctx *ctx, int rc) {
+  ctx->hp_pending = false;
+  (void)fqgpu_sync(ctx);
+  return rc;
+}
+#define FQ_HIP_HP(call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return hp_fail(ctx, fq_hip_error(e_, __FILE__, __LINE__));          \
+  } while (0)
+
+// caller_seq_cap / caller_qual_cap: capacities the overflow rule is judged against (0: the reference's bounds)
+static int hp_encode_begin(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs, size_t n_recs,
+                           unsigned flags, size_t caller_seq_cap, size_t caller_qual_cap, size_t *n_recs_out,
+                           size_t *n_bases_out, size_t *used_len) {
+  if (!ctx || !raw || !raw_len || (recs && !n_recs)) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  ctx->hp_pending = false;  // (a block begun and never collected is dropped: fqgpu_sync below waits for it)
+  size_t n_bases = 0, n_n = 0, used = raw_len;
+  if (recs && (rc = check_recs(recs, n_recs, raw_len, &n_bases))) return rc;
+  if ((rc = fqgpu_sync(ctx))) return rc;
+  fqgpu_dblock *b = nullptr;
+  // the raw buffer first: without a record table the other sizes are known only after the device has counted the lines
+  if ((rc = hp_block_acquire(ctx, raw_len, recs ? n_recs : 0, n_bases, 0, 0, 0, &b))) return rc;
+  if (!ctx->hp_ev_h2d) FQ_HIP(hipEventCreateWithFlags(&ctx->hp_ev_h2d, hipEventDisableTiming));
+  if (!ctx->hp_result) FQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->hp_result), sizeof(BlockResult), hipHostMallocPortable));
+  FQ_HIP_HP(hipMemsetAsync(b->raw + raw_len, 0, 64, ctx->stream));
+  FQ_HIP_HP(hipMemcpyAsync(b->raw, raw, raw_len, hipMemcpyHostToDevice, ctx->stream));
+  if (!recs) {
+    if ((rc = fq_parse_count(ctx->stream, b->raw, raw_len, ctx->hp_parse, &n_recs))) return hp_fail(ctx, rc);
+    if (!hp_grow(b->recs, ctx->hp_recs, n_recs)) return hp_fail(ctx, FQGPU_E_NOMEM);
+    if ((rc = fq_parse_records(ctx->stream, b->raw, raw_len, ctx->hp_parse, b->recs, n_recs, &n_bases, &n_n, &used))) return hp_fail(ctx, rc);
+  }
+  // The reference's capacities are the ones the overflow rule is judged against.  n_pos: the device
+  // parser counted the N's; with a caller's table the worst case (every base an N) is provided for.
+  if ((rc = hp_block_acquire(ctx, used, n_recs, n_bases, caller_seq_cap ? caller_seq_cap : fqgpu_bound_seq(n_bases),
+                             caller_qual_cap ? caller_qual_cap : fqgpu_bound_qual(n_bases), recs ? n_bases : n_n, &b)))
+    return hp_fail(ctx, rc);
+  if (recs) FQ_HIP_HP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, ctx->stream));
+  FQ_HIP_HP(hipEventRecord(ctx->hp_ev_h2d, ctx->stream));
+  b->last_op = 1;
+  b->result_pulled = false;
+  hipStream_t st = nullptr;
+  // (the device copy of raw is scratch here: its N's are patched on the host by fqgpu_encode_end)
+  if ((rc = fq_encode_launch(ctx, b, flags & ~FQGPU_F_WRITE_BACK_N, ctx->hp_ev_h2d, &st))) return hp_fail(ctx, rc);
+  FQ_HIP_HP(hipMemcpyAsync(ctx->hp_result, b->result, sizeof(BlockResult), hipMemcpyDeviceToHost, st));
+  ctx->hp_pending = true;
+  ctx->hp_flags = flags;
+  ctx->hp_done = st;
+  if (n_recs_out) *n_recs_out = n_recs;
+  if (n_bases_out) *n_bases_out = n_bases;
+  if (used_len) *used_len = used;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_encode_begin(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs, size_t n_recs,
+                                  unsigned flags, size_t *n_recs_out, size_t *n_bases_out, size_t *used_len) {
+  return hp_encode_begin(ctx, raw, raw_len, recs, n_recs, flags, 0, 0, n_recs_out, n_bases_out, used_len);
+}
+
+extern "C" int fqgpu_encode_records(fqgpu_ctx *ctx, fqgpu_rec *recs_out, size_t cap) {
+  if (!ctx || !recs_out || !ctx->hp_pending || !ctx->hp_block || cap < ctx->hp_block->n_recs) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  // on the handle's copy stream: the table was built (or uploaded) there; the lanes' kernels are not waited for
+  FQ_HIP(hipMemcpyAsync(recs_out, ctx->hp_block->recs, ctx->hp_block->n_recs * sizeof(fqgpu_rec), hipMemcpyDeviceToHost, ctx->stream));
+  FQ_HIP(hipStreamSynchronize(ctx->stream));
+  return FQGPU_OK;
+}
+
+// waits for the block in flight and reads its result block; the block stays pending
+static int hp_collect(fqgpu_ctx *ctx) {
+  fqgpu_dblock *b = ctx->hp_block;
+  if (b->result_pulled) return FQGPU_OK;
+  FQ_HIP_HP(hipStreamSynchronize(ctx->hp_done));
+  b->host_result = *ctx->hp_result;
+  b->result_pulled = true;
+  const BlockResult &r = b->host_result;
+  if (r.s[0].bad_symbol || r.s[1].bad_symbol) return hp_fail(ctx, FQGPU_E_ARG);
+  if (r.s[0].overflow || r.s[1].overflow) return hp_fail(ctx, FQGPU_E_OVERFLOW);
+  b->seq_len = (size_t)r.s[0].len; b->qual_len = (size_t)r.s[1].len; b->n_pos_len = (size_t)r.n_pos_len;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_encode_wait(fqgpu_ctx *ctx, size_t *seq_len, size_t *qual_len, size_t *n_pos_len) {
+  if (!ctx || !ctx->hp_pending || !ctx->hp_block) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  if ((rc = hp_collect(ctx))) return rc;
+  if (seq_len) *seq_len = ctx->hp_block->seq_len;
+  if (qual_len) *qual_len = ctx->hp_block->qual_len;
+  if (n_pos_len) *n_pos_len = ctx->hp_block->n_pos_len;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_encode_end(fqgpu_ctx *ctx, uint8_t *raw, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
+                                uint8_t *qual_out, size_t qual_cap, size_t *qual_len, uint16_t *readlens_out,
+                                uint16_t *n_count_out, uint16_t *n_pos_out, size_t n_pos_cap, size_t *n_pos_len) {
+  if (!ctx || !ctx->hp_pending || !ctx->hp_block) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  if (!seq_out || !qual_out || !seq_len || !qual_len) return hp_fail(ctx, FQGPU_E_ARG);
+  fqgpu_dblock *b = ctx->hp_block;
+  hipStream_t st = ctx->hp_done;
+  const size_t n_recs = b->n_recs;
+  if ((rc = hp_collect(ctx))) return rc;
+  ctx->hp_pending = false;
+  if (b->seq_len > seq_cap || b->qual_len > qual_cap) return FQGPU_E_OVERFLOW;
+  if (n_pos_out && b->n_pos_len > n_pos_cap) return FQGPU_E_ARG;
+  // N -> A on the host needs the N tables even if the caller does not want them
+  std::vector<uint16_t> tmp_cnt, tmp_pos;
+  const bool patch = raw && (ctx->hp_flags & FQGPU_F_WRITE_BACK_N) && b->n_pos_len;
+  uint16_t *cnt_h = n_count_out, *pos_h = n_pos_out;
+  if (patch && !cnt_h) { tmp_cnt.resize(n_recs); cnt_h = tmp_cnt.data(); }
+  if (patch && !pos_h) { tmp_pos.resize(b->n_pos_len); pos_h = tmp_pos.data(); }
+  std::vector<fqgpu_rec> tmp_recs;
+  if (patch) tmp_recs.resize(n_recs);
+  // (the side buffers -- record table, readlens, n_count, n_pos -- are best left PAGEABLE: as page-locked
+  // buffers their small copies queue up in the DMA engines behind the other workers' 256 MiB uploads;
+  // four threads: 47.9 GB/s with pageable, 40-42 with page-locked side buffers, same box)
+  FQ_HIP_HP(hipMemcpyAsync(seq_out, b->seq, b->seq_len, hipMemcpyDeviceToHost, st));
+  FQ_HIP_HP(hipMemcpyAsync(qual_out, b->qual, b->qual_len, hipMemcpyDeviceToHost, st));
+  if (readlens_out) FQ_HIP_HP(hipMemcpyAsync(readlens_out, b->readlens, n_recs * 2, hipMemcpyDeviceToHost, st));
+  if (cnt_h) FQ_HIP_HP(hipMemcpyAsync(cnt_h, b->n_count, n_recs * 2, hipMemcpyDeviceToHost, st));
+  if (pos_h && b->n_pos_len) FQ_HIP_HP(hipMemcpyAsync(pos_h, b->n_pos, b->n_pos_len * 2, hipMemcpyDeviceToHost, st));
+  if (patch) FQ_HIP_HP(hipMemcpyAsync(tmp_recs.data(), b->recs, n_recs * sizeof(fqgpu_rec), hipMemcpyDeviceToHost, st));
+  FQ_HIP_HP(hipStreamSynchronize(st));
+  if (patch) {  // replaceAndEncodeNs (src/fse_sequence.cpp:35-51): deltas to the previous N, the first one absolute
+    size_t at = 0;
+    for (size_t r = 0; r < n_recs; r++) {
+      uint8_t *s = raw + tmp_recs[r].seq_off;
+      unsigned pos = 0;
+      for (unsigned k = cnt_h[r]; k > 0; k--) { pos += pos_h[at++]; s[pos] = 'A'; }
+    }
+  }
+  *seq_len = b->seq_len;
+  *qual_len = b->qual_len;
+  if (n_pos_len) *n_pos_len = b->n_pos_len;
+  return FQGPU_OK;
+}
+
 // Host-pointer encode, one block per call, as asynchronous as one call can be: the inputs go up on
 // the handle's copy stream, the lane's kernels wait for that event (not for the host), the result
 // block lands in page-locked memory behind the last kernel, and the streams come down with their
@@ -942,63 +1088,12 @@ extern "C" int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, 
                                   uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
                                   size_t n_pos_cap, size_t *n_pos_len, unsigned flags) {
   if (!ctx || !raw || !recs || !n_recs || !seq_out || !qual_out || !seq_len || !qual_len) return FQGPU_E_ARG;
-  int rc = use_device(ctx->device);
+  if (!seq_cap || !qual_cap) return FQGPU_E_ARG;
+  // the caller's capacities are the ones the overflow rule is judged against
+  int rc = hp_encode_begin(ctx, raw, raw_len, recs, n_recs, flags, seq_cap, qual_cap, nullptr, nullptr, nullptr);
   if (rc) return rc;
-  size_t n_bases = 0;
-  if ((rc = check_recs(recs, n_recs, raw_len, &n_bases))) return rc;
-  if ((rc = fqgpu_sync(ctx))) return rc;
-  // The caller's capacities are the ones the overflow rule is judged against.  n_pos is sized
-  // for the worst case (every base an N) instead of pre-counting the N's on the host.
-  fqgpu_dblock *b = nullptr;
-  if ((rc = hp_block_acquire(ctx, raw_len, n_recs, n_bases, seq_cap, qual_cap, n_bases, &b))) return rc;
-  if (!ctx->hp_ev_h2d) FQ_HIP(hipEventCreateWithFlags(&ctx->hp_ev_h2d, hipEventDisableTiming));
-  if (!ctx->hp_result) FQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->hp_result), sizeof(BlockResult), hipHostMallocDefault));
-  FQ_HIP(hipMemcpyAsync(b->raw, raw, raw_len, hipMemcpyHostToDevice, ctx->stream));
-  FQ_HIP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, ctx->stream));
-  FQ_HIP(hipEventRecord(ctx->hp_ev_h2d, ctx->stream));
-  b->last_op = 1;
-  b->result_pulled = false;
-  hipStream_t st = nullptr;
-  // (the device copy of raw is scratch here: its N's are patched on the host below)
-  if ((rc = fq_encode_launch(ctx, b, flags & ~FQGPU_F_WRITE_BACK_N, ctx->hp_ev_h2d, &st))) return rc;
-  FQ_HIP(hipMemcpyAsync(ctx->hp_result, b->result, sizeof(BlockResult), hipMemcpyDeviceToHost, st));
-  FQ_HIP(hipStreamSynchronize(st));
-  b->host_result = *ctx->hp_result;
-  b->result_pulled = true;
-  {
-    const BlockResult &r = b->host_result;
-    if (r.s[0].bad_symbol || r.s[1].bad_symbol) return FQGPU_E_ARG;
-    if (r.s[0].overflow || r.s[1].overflow) return FQGPU_E_OVERFLOW;
-    b->seq_len = (size_t)r.s[0].len; b->qual_len = (size_t)r.s[1].len; b->n_pos_len = (size_t)r.n_pos_len;
-  }
-  if (n_pos_out && b->n_pos_len > n_pos_cap) return FQGPU_E_ARG;
-  // N -> A on the host needs the N tables even if the caller does not want them
-  std::vector<uint16_t> tmp_cnt, tmp_pos;
-  const bool patch = (flags & FQGPU_F_WRITE_BACK_N) && b->n_pos_len;
-  uint16_t *cnt_h = n_count_out, *pos_h = n_pos_out;
-  if (patch && !cnt_h) { tmp_cnt.resize(n_recs); cnt_h = tmp_cnt.data(); }
-  if (patch && !pos_h) { tmp_pos.resize(b->n_pos_len); pos_h = tmp_pos.data(); }
-  // (the side buffers -- record table, readlens, n_count, n_pos -- are best left PAGEABLE: as page-locked
-  // buffers their small copies queue up in the DMA engines behind the other workers' 256 MiB uploads;
-  // four threads: 47.9 GB/s with pageable, 40-42 with page-locked side buffers, same box)
-  FQ_HIP(hipMemcpyAsync(seq_out, b->seq, b->seq_len, hipMemcpyDeviceToHost, st));
-  FQ_HIP(hipMemcpyAsync(qual_out, b->qual, b->qual_len, hipMemcpyDeviceToHost, st));
-  if (readlens_out) FQ_HIP(hipMemcpyAsync(readlens_out, b->readlens, n_recs * 2, hipMemcpyDeviceToHost, st));
-  if (cnt_h) FQ_HIP(hipMemcpyAsync(cnt_h, b->n_count, n_recs * 2, hipMemcpyDeviceToHost, st));
-  if (pos_h && b->n_pos_len) FQ_HIP(hipMemcpyAsync(pos_h, b->n_pos, b->n_pos_len * 2, hipMemcpyDeviceToHost, st));
-  FQ_HIP(hipStreamSynchronize(st));
-  if (patch) {  // replaceAndEncodeNs (src/fse_sequence.cpp:35-51): deltas to the previous N, the first one absolute
-    size_t at = 0;
-    for (size_t r = 0; r < n_recs; r++) {
-      uint8_t *s = raw + recs[r].seq_off;
-      unsigned pos = 0;
-      for (unsigned k = cnt_h[r]; k > 0; k--) { pos += pos_h[at++]; s[pos] = 'A'; }
-    }
-  }
-  *seq_len = b->seq_len;
-  *qual_len = b->qual_len;
-  if (n_pos_len) *n_pos_len = b->n_pos_len;
-  return FQGPU_OK;
+  return fqgpu_encode_end(ctx, raw, seq_out, seq_cap, seq_len, qual_out, qual_cap, qual_len, readlens_out, n_count_out, n_pos_out,
+                          n_pos_cap, n_pos_len);
 }
 
 extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual,
@@ -1019,29 +1114,29 @@ extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq
   // raw_out holds the skeleton the first decode pass laid out (headers, newlines, '+')
   // everything on the handle's stream (the decode kernels run there too): no host wait in between
   hipStream_t st = ctx->stream;
-  FQ_HIP(hipMemcpyAsync(b->raw, raw_out, raw_len, hipMemcpyHostToDevice, st));
-  FQ_HIP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, st));
-  FQ_HIP(hipMemsetAsync(b->seq + seq_len, 0, 16, st));  // the bit reader loads whole dwords
-  FQ_HIP(hipMemsetAsync(b->qual + qual_len, 0, 16, st));
-  FQ_HIP(hipMemcpyAsync(b->seq, seq, seq_len, hipMemcpyHostToDevice, st));
-  FQ_HIP(hipMemcpyAsync(b->qual, qual, qual_len, hipMemcpyHostToDevice, st));
+  FQ_HIP_HP(hipMemcpyAsync(b->raw, raw_out, raw_len, hipMemcpyHostToDevice, st));
+  FQ_HIP_HP(hipMemcpyAsync(b->recs, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice, st));
+  FQ_HIP_HP(hipMemsetAsync(b->seq + seq_len, 0, 16, st));  // the bit reader loads whole dwords
+  FQ_HIP_HP(hipMemsetAsync(b->qual + qual_len, 0, 16, st));
+  FQ_HIP_HP(hipMemcpyAsync(b->seq, seq, seq_len, hipMemcpyHostToDevice, st));
+  FQ_HIP_HP(hipMemcpyAsync(b->qual, qual, qual_len, hipMemcpyHostToDevice, st));
   // the reference pops from the END of n_count (src/fse_sequence.cpp:115-126)
-  FQ_HIP(hipMemcpyAsync(b->n_count, n_count + (n_count_len - n_recs), n_recs * 2, hipMemcpyHostToDevice, st));
-  if (n_pos_len) FQ_HIP(hipMemcpyAsync(b->n_pos, n_pos, n_pos_len * 2, hipMemcpyHostToDevice, st));
+  FQ_HIP_HP(hipMemcpyAsync(b->n_count, n_count + (n_count_len - n_recs), n_recs * 2, hipMemcpyHostToDevice, st));
+  if (n_pos_len) FQ_HIP_HP(hipMemcpyAsync(b->n_pos, n_pos, n_pos_len * 2, hipMemcpyHostToDevice, st));
   b->seq_len = seq_len; b->qual_len = qual_len; b->n_pos_len = n_pos_len;
   b->last_op = 2;
   b->result_pulled = false;
   fqgpu_dblock *one[1] = {b};
-  if ((rc = fq_decode_launch(ctx, one, 1))) return rc;
-  if (!ctx->hp_result) FQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->hp_result), sizeof(BlockResult), hipHostMallocDefault));
+  if ((rc = fq_decode_launch(ctx, one, 1))) return hp_fail(ctx, rc);
+  if (!ctx->hp_result) FQ_HIP_HP(hipHostMalloc(reinterpret_cast<void **>(&ctx->hp_result), sizeof(BlockResult), hipHostMallocPortable));
   // The copies back are issued only when the kernels are through: a copy that waits in a DMA
   // engine's queue for a 13 s decode kernel holds that engine, and the uploads of the next workers'
   // blocks queue up behind it (measured in the block farm: four decoding workers ran two and two,
   // the third worker's fifth hipMemcpyAsync returning after 12.8 s).
-  FQ_HIP(hipStreamSynchronize(st));
-  FQ_HIP(hipMemcpyAsync(ctx->hp_result, b->result, sizeof(BlockResult), hipMemcpyDeviceToHost, st));
-  FQ_HIP(hipMemcpyAsync(raw_out, b->raw, raw_len, hipMemcpyDeviceToHost, st));
-  FQ_HIP(hipStreamSynchronize(st));
+  FQ_HIP_HP(hipStreamSynchronize(st));
+  FQ_HIP_HP(hipMemcpyAsync(ctx->hp_result, b->result, sizeof(BlockResult), hipMemcpyDeviceToHost, st));
+  FQ_HIP_HP(hipMemcpyAsync(raw_out, b->raw, raw_len, hipMemcpyDeviceToHost, st));
+  FQ_HIP_HP(hipStreamSynchronize(st));
   b->host_result = *ctx->hp_result;
   b->result_pulled = true;
   if (b->host_result.s[0].bad_symbol || b->host_result.s[1].bad_symbol) return FQGPU_E_ARG;

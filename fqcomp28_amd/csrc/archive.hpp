@@ -1,15 +1,10 @@
-// archive.hpp -- the reference's `.fqc` block container on top of the shim's buffers
-// (SURVEY.md 8(f) row 2).  Host code; mirrors, name for name:
-//   Archive, BlockInfo, writeBlock / readBlock / writeIndex / meta / indexBytes   src/archive.h:18-96
-//   layout of the file                                                            src/archive.h:10-17
-//   field order inside a block                                                    src/archive.cpp:57-106, 108-163
-//   FastqReader::readNextChunk / FastqWriter::writeChunk                          src/fastq_io.cpp:23-65, 131-143
-//   analyzeDataset                                                                src/prepare.cpp:42-47
+// archive.hpp -- the `.fqc` container and the FASTQ file ends of the block farm, written from the
+// FORMAT (reference src/archive.h:10-17 states it; src/archive.cpp:45-55, 57-106 and
+// src/prepare.cpp:12-21 fill it in), for a farm of many workers per GPU:
 //
-// File layout (all integers little-endian, as the reference writes them from memory):
-//   u32  n_blocks                      written LAST, at offset 0 (writeIndex, src/archive.cpp:45-55)
+//   u32  n_blocks                      at offset 0, known only at the end
 //   meta u16 hlen | first header | FreqTable<256,4> (3076 B) | FreqTable<8192,64> (1 081 348 B)
-//   block x n_blocks, in COMPLETION order:
+//   block x n_blocks, in the order their space was claimed:
 //        u32 total | u32 n_records
 //        u32 orig | u32 csize | bytes          readlens
 //        u32 orig | u32 csize | bytes          n_count
@@ -18,17 +13,37 @@
 //        u32 csize | bytes                     qual
 //        per header field: STRING  3 x (u32 orig | u32 csize | bytes)  flags, content, lengths
 //                          NUMERIC 1 x (u32 orig | u32 csize | bytes)  content
-//   index: n_blocks x { i64 offset; u32 idx; 4 bytes of padding }  = sizeof(BlockInfo) = 16
-// Byte-compatible with the reference for every field except the csize/bytes of the misc streams,
-// which hold this library's own coder's output instead of libbsc's (out of parity scope).
+//   index: n_blocks x { i64 offset; u32 idx; 4 zero bytes }, ascending offsets
+// (all integers little-endian).  Byte-compatible with the reference for every field except the
+// csize/bytes of the misc streams, which hold this library's own coder's output instead of libbsc's.
+//
+// What is different from the reference's classes of the same names (src/archive.h:18-96,
+// src/fastq_io.h:10-59), and why -- its reader parses every chunk and its archive and writer move
+// every byte under ONE mutex each (src/fastq_io.cpp:29-52, src/archive.cpp:57-106,
+// src/fastq_io.cpp:131-143), which is what bounds a farm whose coder takes 3 ms per block:
+//   * files are positional (pread / pwrite on a descriptor): no cursor, hence nothing to lock around
+//     the bytes.  A block is serialised into ONE buffer from a field list (blockFields: the one
+//     place that knows the order; writer and reader both walk it), claims its space with one atomic
+//     add and goes out with one pwrite; a block comes in with one pread of its extent and is taken
+//     apart by a bounds-checked cursor.
+//   * FastqReader only FINDS the end of a chunk under its lock -- a backwards search for the last
+//     complete record in the last megabyte of the range -- the bulk of the chunk is read outside,
+//     and the chunk goes to the GPU unparsed (fqgpu_encode_begin builds the record table).
+//   * FastqWriter knows where every chunk goes (the archive's blocks carry their original sizes):
+//     chunks are written wherever they belong the moment they are ready; no worker waits for another.
+//   * abort(): a worker that fails stops the others at their next block instead of leaving them waiting.
 #pragma once
 
 #include <algorithm>
-#include <condition_variable>
-#include <cstdio>
+#include <atomic>
+#include <cerrno>
 #include <filesystem>
-#include <fstream>
 #include <mutex>
+#include <system_error>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "workspace.hpp"
 
@@ -36,257 +51,385 @@ namespace fqcomp28 {
 
 using path_t = std::filesystem::path;
 
-inline void checkStreamState(std::ios &s, const path_t &path) {  // src/utils.cpp:4-7
-  if (!s.good()) throw std::system_error(std::make_error_code(std::errc::io_error), path.string());
-}
-
-template <class Target, class Source> Target narrow_cast(Source v) {  // src/utils.h:17-23
-  auto r = static_cast<Target>(v);
-  if (static_cast<Source>(r) != v) throw std::runtime_error("narrow_cast<>() failed");
-  return r;
-}
-
-/** Reads data from a single .fastq file (src/fastq_io.h:10-42): chunks of about reading_size
- *  bytes that end with a complete record; the partial record at the end is carried over */
-class FastqReader {
+/** A file addressed by position; any number of threads. */
+class PosFile {
 public:
-  FastqReader(const std::string &mates1, std::size_t reading_size)
-      : reading_size_(reading_size), ifs1_(mates1, std::ios::binary), bytes_left1_(std::filesystem::file_size(mates1)) {
-    checkStreamState(ifs1_, mates1);
+  enum class Mode { Read, Create };
+  PosFile(const path_t &p, Mode m) : path_(p.string()) {
+    fd_ = m == Mode::Read ? ::open(path_.c_str(), O_RDONLY) : ::open(path_.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd_ < 0) fail("open");
+  }
+  ~PosFile() { if (fd_ >= 0) ::close(fd_); }
+  PosFile(const PosFile &) = delete;
+  PosFile &operator=(const PosFile &) = delete;
+
+  [[nodiscard]] uint64_t size() const {
+    struct stat st;
+    if (::fstat(fd_, &st) != 0) fail("fstat");
+    return static_cast<uint64_t>(st.st_size);
+  }
+  /** exactly n bytes from off, or an exception */
+  void readAt(uint64_t off, void *dst, std::size_t n) const {
+    char *p = static_cast<char *>(dst);
+    while (n) {
+      const ssize_t got = ::pread(fd_, p, n, static_cast<off_t>(off));
+      if (got < 0 && errno == EINTR) continue;
+      if (got <= 0) throw std::runtime_error(path_ + ": file ends inside a read of " + std::to_string(n) + " bytes at " + std::to_string(off));
+      p += got; off += static_cast<uint64_t>(got); n -= static_cast<std::size_t>(got);
+    }
+  }
+  void writeAt(uint64_t off, const void *src, std::size_t n) {
+    const char *p = static_cast<const char *>(src);
+    while (n) {
+      const ssize_t put = ::pwrite(fd_, p, n, static_cast<off_t>(off));
+      if (put < 0 && errno == EINTR) continue;
+      if (put <= 0) fail("pwrite");
+      p += put; off += static_cast<uint64_t>(put); n -= static_cast<std::size_t>(put);
+    }
+  }
+  void resize(uint64_t n) { if (::ftruncate(fd_, static_cast<off_t>(n)) != 0) fail("ftruncate"); }
+
+private:
+  [[noreturn]] void fail(const char *what) const { throw std::system_error(errno, std::generic_category(), path_ + ": " + what); }
+  std::string path_;
+  int fd_ = -1;
+};
+
+namespace blockfmt {
+constexpr std::size_t INDEX_ENTRY = 16;  // i64 offset | u32 idx | 4 zero bytes
+
+/** The sized fields of a block in file order, each as f(orig, bytes): orig points at the u32 in
+ *  front of the field's size, or is null for the two FSE streams, which carry no original size. */
+template <class Buffers, class F> void blockFields(Buffers &cb, const headers::HeaderFormatSpeciciation &fmt, F &&f) {
+  uint32_t *const none = nullptr;
+  f(&cb.original_size.readlens, cb.compressed_readlens);
+  f(&cb.original_size.n_count, cb.compressed_n_count);
+  f(&cb.original_size.n_pos, cb.compressed_n_pos);
+  f(none, cb.seq);
+  f(none, cb.qual);
+  for (std::size_t i = 0; i < fmt.n_fields(); ++i) {
+    auto &sizes = cb.original_size.header_fields[i];
+    auto &streams = cb.compressed_header_fields[i];
+    if (fmt.field_types[i] == headers::FieldType::STRING) {
+      f(&sizes.isDifferentFlag, streams.isDifferentFlag);
+      f(&sizes.content, streams.content);
+      f(&sizes.contentLength, streams.contentLength);
+    } else {
+      f(&sizes.content, streams.content);
+    }
+  }
+}
+
+inline void put32(uint8_t *&p, uint32_t v) { std::memcpy(p, &v, 4); p += 4; }
+
+/** read side: nothing is taken from beyond `end` */
+struct Cursor {
+  const uint8_t *p, *end;
+  uint32_t u32() {
+    if (end - p < 4) throw std::runtime_error("archive block: truncated");
+    uint32_t v;
+    std::memcpy(&v, p, 4);
+    p += 4;
+    return v;
+  }
+  template <class Bytes> void bytes(Bytes &dst) {
+    const uint32_t n = u32();
+    if (static_cast<std::size_t>(end - p) < n) throw std::runtime_error("archive block: a field runs past the block");
+    dst.resize(n);
+    if (n) std::memcpy(dst.data(), p, n);
+    p += n;
+  }
+};
+}  // namespace blockfmt
+
+/** The archive's own view of an index entry (16 bytes in the file) */
+struct BlockRef {
+  uint64_t offset = 0, end = 0;  // extent of the block in the file
+  uint32_t idx = 0;              // position of its chunk in the input
+};
+
+class Archive {
+public:
+  /** an existing archive, to read */
+  explicit Archive(const path_t &archive_path) : file_(archive_path, PosFile::Mode::Read) { load(); }
+  /** a new archive whose tables come from the first sample_size_bytes of a FASTQ file */
+  Archive(const path_t &archive_path, const path_t &file_to_gather_meta, std::size_t sample_size_bytes, int device = 0);
+  /** ... or are handed over */
+  Archive(const path_t &archive_path, DatasetMeta meta) : file_(archive_path, PosFile::Mode::Create), meta_(std::move(meta)) {
+    std::vector<uint8_t> head(sizeof(uint32_t), 0);  // the block count: filled in by writeIndex
+    meta_.appendTo(head);
+    file_.writeAt(0, head.data(), head.size());
+    claim_.store(head.size());
   }
 
-  /** @return true if reading was successful */
-  bool readNextChunk(FastqChunk &chunk) {
-    chunk.clear();
-    const std::lock_guard guard(mtx_);
-    if (bytes_left1_ == 0) return false;  // (a partial record left at the very end is dropped like in the reference)
-    chunk.idx = chunks_read_++;           // under the lock: the reference increments before it
-    const std::size_t to_read = std::min(reading_size_ - partial1_.size(), bytes_left1_);
-    chunk.raw_data.resize(partial1_.size() + to_read);
-    char *buf = chunk.raw_data.data();
-    std::memcpy(buf, partial1_.data(), partial1_.size());
-    buf += partial1_.size();
-    partial1_.clear();
-    ifs1_.read(buf, static_cast<std::streamsize>(to_read));
-    if (!ifs1_) throw std::runtime_error("FastqReader: short read");
-    const std::size_t actual_chunk_size = parseRecords(chunk);
-    partial1_.assign(chunk.raw_data.begin() + static_cast<std::ptrdiff_t>(actual_chunk_size), chunk.raw_data.end());
-    chunk.raw_data.resize(actual_chunk_size);
-    bytes_left1_ -= to_read;
-    if (chunk.records.empty()) throw std::runtime_error("FastqReader: reading size smaller than one record");
+  /** Thread-safe; concurrent callers write concurrently. */
+  void writeBlock(const CompressedBuffersDst &cb) {
+    const auto &fmt = meta_.header_fmt;
+    if (cb.compressed_header_fields.size() != fmt.n_fields() || cb.original_size.header_fields.size() != fmt.n_fields())
+      throw std::invalid_argument("writeBlock: header field streams do not match the archive's format");
+    std::size_t bytes = 2 * sizeof(uint32_t);
+    blockfmt::blockFields(cb, fmt, [&](const uint32_t *orig, const auto &data) {
+      if (data.size() > 0xFFFFFFFFull) throw std::length_error("writeBlock: a field of 4 GiB or more");
+      bytes += (orig ? 8 : 4) + data.size();
+    });
+    std::vector<uint8_t> image(bytes);
+    uint8_t *p = image.data();
+    blockfmt::put32(p, cb.original_size.total);
+    blockfmt::put32(p, cb.original_size.n_records);
+    blockfmt::blockFields(cb, fmt, [&](const uint32_t *orig, const auto &data) {
+      if (orig) blockfmt::put32(p, *orig);
+      blockfmt::put32(p, static_cast<uint32_t>(data.size()));
+      if (!data.empty()) std::memcpy(p, data.data(), data.size());
+      p += data.size();
+    });
+    BlockRef ref;
+    ref.offset = claim_.fetch_add(bytes);
+    ref.end = ref.offset + bytes;
+    ref.idx = cb.chunk_idx;
+    file_.writeAt(ref.offset, image.data(), bytes);
+    const std::lock_guard<std::mutex> guard(index_mutex_);
+    index_.push_back(ref);
+  }
+
+  /** Thread-safe; blocks are handed out in the order of the input file.  false: no block left (or abort()). */
+  bool readBlock(CompressedBuffersSrc &cb) {
+    cb.clear();
+    if (aborted_.load()) return false;
+    const std::size_t k = next_.fetch_add(1);
+    if (k >= index_.size()) return false;
+    const BlockRef &ref = index_[k];
+    std::vector<uint8_t> image(ref.end - ref.offset);
+    file_.readAt(ref.offset, image.data(), image.size());
+    blockfmt::Cursor cur{image.data(), image.data() + image.size()};
+    const auto &fmt = meta_.header_fmt;
+    cb.chunk_idx = ref.idx;
+    cb.original_size.total = cur.u32();
+    cb.original_size.n_records = cur.u32();
+    cb.original_size.header_fields.assign(fmt.n_fields(), {});
+    cb.compressed_header_fields.resize(fmt.n_fields());
+    cb.header_fields.resize(fmt.n_fields());
+    blockfmt::blockFields(cb, fmt, [&](uint32_t *orig, auto &data) {
+      if (orig) *orig = cur.u32();
+      cur.bytes(data);
+    });
     return true;
   }
 
+  /** the index behind the last block, then the block count at offset 0 */
+  void writeIndex() {
+    const std::lock_guard<std::mutex> guard(index_mutex_);
+    if (index_.size() > 0xFFFFFFFFull) throw std::length_error("writeIndex: too many blocks");
+    std::sort(index_.begin(), index_.end(), [](const BlockRef &a, const BlockRef &b) { return a.offset < b.offset; });
+    std::vector<uint8_t> tail(index_.size() * blockfmt::INDEX_ENTRY, 0);
+    for (std::size_t i = 0; i < index_.size(); ++i) {
+      const int64_t off = static_cast<int64_t>(index_[i].offset);
+      std::memcpy(tail.data() + i * blockfmt::INDEX_ENTRY, &off, 8);
+      std::memcpy(tail.data() + i * blockfmt::INDEX_ENTRY + 8, &index_[i].idx, 4);
+    }
+    file_.writeAt(claim_.load(), tail.data(), tail.size());
+    const uint32_t n = static_cast<uint32_t>(index_.size());
+    file_.writeAt(0, &n, sizeof(n));
+  }
+  void flush() {}  // (nothing is buffered on this side of the descriptor)
+  /** readBlock hands out nothing more: a worker has failed */
+  void abort() { aborted_.store(true); }
+
+  const DatasetMeta &meta() const { return meta_; }
+  [[nodiscard]] std::size_t indexBytes() const { return sizeof(uint32_t) + index_.size() * blockfmt::INDEX_ENTRY; }
+  [[nodiscard]] std::size_t nBlocks() const { return index_.size(); }
+  /** (offset, idx) of every block, in the order blocks are handed out -- for tests */
+  [[nodiscard]] std::vector<std::pair<int64_t, uint32_t>> indexEntries() const {
+    std::vector<std::pair<int64_t, uint32_t>> v;
+    for (const BlockRef &b : index_) v.emplace_back(static_cast<int64_t>(b.offset), b.idx);
+    return v;
+  }
+  /** Where every chunk starts in the restored file (entry k: chunk k; one more entry: the file's
+   *  size): the first word of a block is the size of its chunk. */
+  [[nodiscard]] std::vector<uint64_t> chunkOffsets() const {
+    std::vector<uint64_t> at(index_.size() + 1, 0);
+    for (std::size_t k = 0; k < index_.size(); ++k) {
+      uint32_t total = 0;
+      file_.readAt(index_[k].offset, &total, sizeof(total));
+      at[k + 1] = at[k] + total;
+    }
+    return at;
+  }
+
 private:
-  const std::size_t reading_size_;
-  std::vector<char> partial1_;
-  std::ifstream ifs1_;
-  std::size_t bytes_left1_;
-  unsigned chunks_read_ = 0;
-  std::mutex mtx_;
+  void load() {
+    const uint64_t size = file_.size();
+    uint8_t head[6];
+    file_.readAt(0, head, sizeof(head));
+    uint32_t n_blocks;
+    uint16_t hlen;
+    std::memcpy(&n_blocks, head, 4);
+    std::memcpy(&hlen, head + 4, 2);
+    std::vector<uint8_t> m(sizeof(hlen) + hlen + FQGPU_SEQ_FT_BYTES + FQGPU_QUAL_FT_BYTES);
+    file_.readAt(sizeof(uint32_t), m.data(), m.size());
+    meta_ = DatasetMeta::fromBytes(m.data(), m.size());
+    const uint64_t data_begin = sizeof(uint32_t) + m.size(), index_bytes = static_cast<uint64_t>(n_blocks) * blockfmt::INDEX_ENTRY;
+    if (size < data_begin + index_bytes) throw std::runtime_error("archive: the index does not fit the file (truncated?)");
+    const uint64_t index_begin = size - index_bytes;
+    std::vector<uint8_t> tail(index_bytes);
+    if (index_bytes) file_.readAt(index_begin, tail.data(), tail.size());
+    index_.resize(n_blocks);
+    for (std::size_t i = 0; i < n_blocks; ++i) {
+      int64_t off;
+      std::memcpy(&off, tail.data() + i * blockfmt::INDEX_ENTRY, 8);
+      std::memcpy(&index_[i].idx, tail.data() + i * blockfmt::INDEX_ENTRY + 8, 4);
+      if (off < static_cast<int64_t>(data_begin) || static_cast<uint64_t>(off) + 2 * sizeof(uint32_t) > index_begin)
+        throw std::runtime_error("archive: a block offset lies outside the data section");
+      index_[i].offset = static_cast<uint64_t>(off);
+    }
+    // a block ends where the next one in the file begins
+    std::vector<std::size_t> by_offset(n_blocks);
+    for (std::size_t i = 0; i < n_blocks; ++i) by_offset[i] = i;
+    std::sort(by_offset.begin(), by_offset.end(), [&](std::size_t a, std::size_t b) { return index_[a].offset < index_[b].offset; });
+    for (std::size_t r = 0; r < n_blocks; ++r)
+      index_[by_offset[r]].end = r + 1 < n_blocks ? index_[by_offset[r + 1]].offset : index_begin;
+    // and blocks are read in the order of their chunks in the input
+    std::stable_sort(index_.begin(), index_.end(), [](const BlockRef &a, const BlockRef &b) { return a.idx < b.idx; });
+    claim_.store(index_begin);
+  }
+
+  PosFile file_;
+  DatasetMeta meta_;
+  std::vector<BlockRef> index_;
+  std::mutex index_mutex_;
+  std::atomic<uint64_t> claim_{0};     // writing: first byte behind the blocks so far
+  std::atomic<std::size_t> next_{0};   // reading: next block to hand out
+  std::atomic<bool> aborted_{false};
 };
 
-/** Writes data to a single .fastq file, chunks in their original order (src/fastq_io.h:44-59) */
+/** Offset behind the last complete 4-line record that ends inside [buf, buf + n); 0 if there is none.
+ *  `starts_at_line`: buf begins at the start of a line (else the bytes before its first newline belong
+ *  to a line that began earlier and are skipped).  A record is recognised from its shape alone --
+ *  '@' line, line, '+' line, line of the second line's length -- which is unambiguous for FASTQ whose
+ *  sequence lines hold bases: shifted by one, two or three lines the '@' / '+' tests look at a
+ *  sequence line (the coder refuses anything but ACGTN there, fqgpu.h). */
+inline std::size_t lastRecordEnd(const char *buf, std::size_t n, bool starts_at_line) {
+  // line ends, from the back: e[0] is the last newline, e[1] the one before ...
+  std::size_t e[5];
+  int have = 0;
+  std::size_t scan = n;
+  auto pull = [&]() -> bool {  // one more newline towards the front
+    while (scan > 0) {
+      const void *hit = ::memrchr(buf, '\n', scan);
+      if (!hit) { scan = 0; return false; }
+      scan = static_cast<std::size_t>(static_cast<const char *>(hit) - buf);
+      return true;
+    }
+    return false;
+  };
+  for (;;) {
+    // window of five newlines: lines 1..4 of a candidate record lie between them
+    while (have < 5) {
+      if (!pull()) break;
+      e[have++] = scan;
+    }
+    if (have < 4) return 0;
+    const bool front_known = have == 5;
+    if (!front_known && !starts_at_line) return 0;  // the first line's start is not in the buffer
+    const std::size_t l1 = front_known ? e[4] + 1 : 0, l2 = e[3] + 1, l3 = e[2] + 1, l4 = e[1] + 1;
+    if (buf[l1] == '@' && buf[l3] == '+' && e[2] - l2 == e[0] - l4) return e[0] + 1;
+    if (!front_known) return 0;
+    // slide the window one line towards the front
+    for (int i = 0; i < 4; ++i) e[i] = e[i + 1];
+    have = 4;
+  }
+}
+
+/** Chunks of a FASTQ file: about reading_size bytes each, whole records only, the next chunk begins
+ *  where the last one ended -- the blocks the reference's reader cuts (src/fastq_io.cpp:23-65), found
+ *  without parsing them.  The chunk arrives UNPARSED (records empty): fqgpu_encode_begin builds the
+ *  record table on the GPU.  Thread-safe; only the search for the chunk's end is serial. */
+class FastqReader {
+public:
+  FastqReader(const path_t &mates1, std::size_t reading_size)
+      : file_(mates1, PosFile::Mode::Read), size_(file_.size()), reading_size_(reading_size) {
+    if (reading_size_ == 0) throw std::invalid_argument("FastqReader: empty reading size");
+  }
+
+  /** @return false when the file is used up (a partial record at its very end is dropped) or after abort() */
+  bool readNextChunk(FastqChunk &chunk) {
+    chunk.clear();
+    uint64_t begin, end;
+    {
+      const std::lock_guard<std::mutex> guard(mutex_);
+      if (aborted_ || next_begin_ >= size_) return false;
+      begin = next_begin_;
+      const uint64_t limit = std::min<uint64_t>(size_, begin + reading_size_);
+      end = begin + findEnd(begin, limit);
+      if (end == begin) {
+        if (limit == size_) { next_begin_ = size_; return false; }
+        throw std::runtime_error("FastqReader: reading size smaller than one record");
+      }
+      next_begin_ = end;
+      chunk.idx = chunks_read_++;
+    }
+    chunk.raw_data.resize(end - begin);
+    file_.readAt(begin, chunk.raw_data.data(), chunk.raw_data.size());
+    return true;
+  }
+  void abort() {
+    const std::lock_guard<std::mutex> guard(mutex_);
+    aborted_ = true;
+  }
+
+private:
+  /** bytes of [begin, limit) up to the end of its last complete record */
+  std::size_t findEnd(uint64_t begin, uint64_t limit) {
+    for (std::size_t window = std::size_t(1) << 20;; window <<= 2) {
+      const uint64_t from = limit - begin > window ? limit - window : begin;
+      tail_.resize(limit - from);
+      file_.readAt(from, tail_.data(), tail_.size());
+      const std::size_t rel = lastRecordEnd(tail_.data(), tail_.size(), from == begin);
+      if (rel) return static_cast<std::size_t>(from - begin) + rel;
+      if (from == begin) return 0;
+    }
+  }
+
+  PosFile file_;
+  const uint64_t size_;
+  const std::size_t reading_size_;
+  std::mutex mutex_;
+  uint64_t next_begin_ = 0;
+  unsigned chunks_read_ = 0;
+  bool aborted_ = false;
+  std::vector<char> tail_;
+};
+
+/** The restored FASTQ file.  chunk_offsets (Archive::chunkOffsets) says where every chunk goes, so
+ *  chunks are written as they come, by any number of threads, in any order. */
 class FastqWriter {
 public:
-  explicit FastqWriter(const std::string &mates1) : ofs1_(mates1, std::ios::binary) { checkStreamState(ofs1_, mates1); }
-  void writeChunk(FastqChunk const &chunk) {
-    std::unique_lock guard(mtx_);
-    cv_.wait(guard, [&] { return chunk.idx == chunks_written_; });
-    ofs1_.write(chunk.raw_data.data(), static_cast<std::streamsize>(chunk.raw_data.size()));
-    chunks_written_++;
-    guard.unlock();
-    cv_.notify_all();
+  FastqWriter(const path_t &mates1, std::vector<uint64_t> chunk_offsets)
+      : file_(mates1, PosFile::Mode::Create), at_(std::move(chunk_offsets)) {
+    if (at_.empty()) at_.push_back(0);
+    file_.resize(at_.back());
   }
-  void flush() { ofs1_.flush(); }
+  void writeChunk(const FastqChunk &chunk) {
+    if (chunk.idx + 1 >= at_.size() || at_[chunk.idx + 1] - at_[chunk.idx] != chunk.raw_data.size())
+      throw std::runtime_error("FastqWriter: chunk " + std::to_string(chunk.idx) + " does not have the size the archive recorded");
+    file_.writeAt(at_[chunk.idx], chunk.raw_data.data(), chunk.raw_data.size());
+  }
+  void flush() {}
 
 private:
-  std::ofstream ofs1_;
-  unsigned chunks_written_ = 0;
-  std::mutex mtx_;
-  std::condition_variable cv_;
+  PosFile file_;
+  std::vector<uint64_t> at_;
 };
 
-/** analyzeDataset (src/prepare.cpp:42-47): the first sample_size_bytes of the file, tables on the GPU */
+/** Dataset analysis (src/prepare.cpp:42-47): the tables of the first sample_size_bytes of the file, on the GPU */
 inline DatasetMeta analyzeDataset(const path_t &fastq_file, std::size_t sample_size_bytes, int device = 0) {
   FastqChunk chunk;
-  FastqReader reader(fastq_file.string(), sample_size_bytes);
+  FastqReader reader(fastq_file, sample_size_bytes);
   if (!reader.readNextChunk(chunk)) throw std::runtime_error("analyzeDataset: empty input");
+  parseRecords(chunk);
   return DatasetMeta(chunk, device);
 }
 
-class Archive {
-  /** Describes location and size of a data block in the archive file (src/archive.h:20-27) */
-  struct BlockInfo {
-    int64_t offset;
-    uint32_t idx;  // position (order) of the corresponding chunk in the input file
-    uint32_t pad_; // the reference's struct has 4 bytes of tail padding here; written as zeros
-    bool operator==(const BlockInfo &o) const { return offset == o.offset && idx == o.idx; }
-  };
-  static_assert(sizeof(BlockInfo) == 16, "index entries are 16 bytes in the reference");
-  constexpr static std::streamoff OFFSET_META = sizeof(uint32_t);
-
-public:
-  /** Creates Archive to read compressed data from an existing file (src/archive.cpp:6-11) */
-  explicit Archive(const path_t &archive_path) : fs_(archive_path, std::ios_base::binary | std::ios_base::in) {
-    checkStreamState(fs_, archive_path);
-    readArchiveHeader();
-  }
-  /** Creates an archive to write compressed data to; meta gathered from the first
-   *  sample_size_bytes of file_to_gather_meta (src/archive.cpp:13-20) */
-  Archive(const path_t &archive_path, const path_t &file_to_gather_meta, std::size_t sample_size_bytes, int device = 0)
-      : Archive(archive_path, analyzeDataset(file_to_gather_meta, sample_size_bytes, device)) {}
-  /** ... or handed over (tables computed elsewhere) */
-  Archive(const path_t &archive_path, DatasetMeta meta)
-      : fs_(archive_path, std::ios_base::binary | std::ios_base::out | std::ios_base::trunc), meta_(std::move(meta)) {
-    checkStreamState(fs_, archive_path);
-    writeMeta();
-  }
-
-  /** src/archive.cpp:57-106 */
-  void writeBlock(const CompressedBuffersDst &cb) {
-    BlockInfo binfo = {};
-    binfo.idx = cb.chunk_idx;
-    const std::lock_guard guard(mtx_);
-    binfo.offset = narrow_cast<int64_t>(static_cast<std::streamoff>(fs_.tellp()));
-    writeInteger(cb.original_size.total);
-    writeInteger(cb.original_size.n_records);
-    writeInteger(cb.original_size.readlens);
-    writeBytes(cb.compressed_readlens);
-    writeInteger(cb.original_size.n_count);
-    writeBytes(cb.compressed_n_count);
-    writeInteger(cb.original_size.n_pos);
-    writeBytes(cb.compressed_n_pos);
-    writeBytes(cb.seq);
-    writeBytes(cb.qual);
-    if (cb.compressed_header_fields.size() != meta_.header_fmt.n_fields() ||
-        cb.original_size.header_fields.size() != meta_.header_fmt.n_fields())
-      throw std::invalid_argument("writeBlock: header field streams do not match the archive's format");
-    for (std::size_t i = 0, E = meta_.header_fmt.n_fields(); i < E; ++i) {
-      const auto &field_cdata = cb.compressed_header_fields[i];
-      const auto &field_original_size = cb.original_size.header_fields[i];
-      if (meta_.header_fmt.field_types[i] == headers::FieldType::STRING) {
-        writeInteger(field_original_size.isDifferentFlag);
-        writeBytes(field_cdata.isDifferentFlag);
-        writeInteger(field_original_size.content);
-        writeBytes(field_cdata.content);
-        writeInteger(field_original_size.contentLength);
-        writeBytes(field_cdata.contentLength);
-      } else {
-        writeInteger(field_original_size.content);
-        writeBytes(field_cdata.content);
-      }
-    }
-    index_.push_back(binfo);
-  }
-
-  /** src/archive.cpp:108-163; blocks come in the order of the input file (sorted index) */
-  bool readBlock(CompressedBuffersSrc &cb) {
-    cb.clear();
-    const std::lock_guard guard(mtx_);
-    if (blocks_processed_ == index_.size()) return false;
-    const auto &binfo = index_[blocks_processed_++];
-    fs_.seekg(binfo.offset);
-    cb.chunk_idx = binfo.idx;
-    cb.original_size.total = readInteger<uint32_t>();
-    cb.original_size.n_records = readInteger<uint32_t>();
-    cb.original_size.readlens = readInteger<uint32_t>();
-    readBytes(cb.compressed_readlens);
-    cb.original_size.n_count = readInteger<uint32_t>();
-    readBytes(cb.compressed_n_count);
-    cb.original_size.n_pos = readInteger<uint32_t>();
-    readBytes(cb.compressed_n_pos);
-    readBytes(cb.seq);
-    readBytes(cb.qual);
-    const auto n_fields = meta_.header_fmt.n_fields();
-    cb.original_size.header_fields.resize(n_fields);
-    cb.header_fields.resize(n_fields);
-    cb.compressed_header_fields.resize(n_fields);
-    for (std::size_t i = 0; i < n_fields; ++i) {
-      auto &field_original_size = cb.original_size.header_fields[i];
-      auto &field_cdata = cb.compressed_header_fields[i];
-      field_original_size = {};
-      if (meta_.header_fmt.field_types[i] == headers::FieldType::STRING) {
-        field_original_size.isDifferentFlag = readInteger<uint32_t>();
-        readBytes(field_cdata.isDifferentFlag);
-        field_original_size.content = readInteger<uint32_t>();
-        readBytes(field_cdata.content);
-        field_original_size.contentLength = readInteger<uint32_t>();
-        readBytes(field_cdata.contentLength);
-      } else {
-        field_original_size.content = readInteger<uint32_t>();
-        readBytes(field_cdata.content);
-      }
-    }
-    if (!fs_.good()) throw std::runtime_error("readBlock: truncated archive");
-    return true;
-  }
-
-  /** src/archive.cpp:45-55: the block count goes to offset 0, the index behind the last block */
-  void writeIndex() {
-    const std::lock_guard guard(mtx_);
-    const std::streamoff data_end_pos = fs_.tellp();
-    fs_.seekp(0);
-    const auto index_size = narrow_cast<uint32_t>(index_.size());
-    writeInteger(index_size);
-    fs_.seekp(data_end_pos);
-    fs_.write(reinterpret_cast<const char *>(index_.data()), narrow_cast<std::streamsize>(index_.size() * sizeof(BlockInfo)));
-  }
-  void flush() { fs_.flush(); }
-
-  const DatasetMeta &meta() const { return meta_; }
-  [[nodiscard]] std::size_t indexBytes() const { return sizeof(uint32_t) + index_.size() * sizeof(BlockInfo); }
-  [[nodiscard]] std::size_t nBlocks() const { return index_.size(); }
-  /** (offset, idx) of every block, in index order -- for tests (the reference's ArchiveTester) */
-  [[nodiscard]] std::vector<std::pair<int64_t, uint32_t>> indexEntries() const {
-    std::vector<std::pair<int64_t, uint32_t>> v;
-    for (const auto &b : index_) v.emplace_back(b.offset, b.idx);
-    return v;
-  }
-
-private:
-  void writeMeta() {  // src/archive.cpp:22-25
-    fs_.seekp(OFFSET_META);
-    DatasetMeta::storeToStream(meta_, fs_);
-  }
-  void readArchiveHeader() {  // src/archive.cpp:27-43
-    uint32_t n_blocks = 0;
-    fs_.read(reinterpret_cast<char *>(&n_blocks), sizeof(n_blocks));
-    meta_ = DatasetMeta::loadFromStream(fs_);
-    const auto data_start_pos = fs_.tellg();
-    fs_.seekg(-narrow_cast<std::streamoff>(static_cast<std::size_t>(n_blocks) * sizeof(BlockInfo)), std::ios_base::end);
-    index_.resize(n_blocks);
-    fs_.read(reinterpret_cast<char *>(index_.data()), narrow_cast<std::streamsize>(static_cast<std::size_t>(n_blocks) * sizeof(BlockInfo)));
-    if (!fs_.good()) throw std::runtime_error("archive header or index truncated");
-    fs_.seekg(data_start_pos);
-    sortIndex();
-  }
-  template <class Vec> void writeBytes(const Vec &bytes) {
-    const auto sz = narrow_cast<uint32_t>(bytes.size());
-    writeInteger(sz);
-    fs_.write(reinterpret_cast<const char *>(bytes.data()), sz);
-  }
-  template <class Vec> void readBytes(Vec &bytes) {
-    const auto sz = readInteger<uint32_t>();
-    bytes.resize(sz);
-    fs_.read(reinterpret_cast<char *>(bytes.data()), sz);
-  }
-  template <class T> void writeInteger(const T val) { fs_.write(reinterpret_cast<const char *>(&val), sizeof(T)); }
-  template <class T> T readInteger() {
-    T ret{};
-    fs_.read(reinterpret_cast<char *>(&ret), sizeof(T));
-    return ret;
-  }
-  /** index entries in the order of the corresponding input chunks (src/archive.h:85-89) */
-  void sortIndex() {
-    std::sort(index_.begin(), index_.end(), [](const auto &l, const auto &r) { return l.idx < r.idx; });
-  }
-
-  std::vector<BlockInfo> index_;
-  std::size_t blocks_processed_ = 0;
-  std::fstream fs_;
-  DatasetMeta meta_;
-  std::mutex mtx_;
-};
+inline Archive::Archive(const path_t &archive_path, const path_t &file_to_gather_meta, std::size_t sample_size_bytes, int device)
+    : Archive(archive_path, analyzeDataset(file_to_gather_meta, sample_size_bytes, device)) {}
 
 }  // namespace fqcomp28

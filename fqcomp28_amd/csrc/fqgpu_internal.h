@@ -103,6 +103,12 @@ struct DevBuf {
 
 struct KernelTimer;  // api.cpp
 
+// grow-only scratch of the device record parser (parse.hip)
+struct ParseScratch {
+  DevBuf cnt, base, sum, nl_pos, scan_tmp;
+  size_t total_nl = 0;  // newlines counted by fq_parse_count
+};
+
 // Scratch of the encode pipeline for one stream.
 struct EncScratch {
   DevBuf slot_of;     // u32 [M]   sorted position of every symbol (encode order)
@@ -169,6 +175,10 @@ struct fqgpu_ctx {
   size_t hp_raw = 0, hp_recs = 0, hp_seq = 0, hp_qual = 0, hp_side = 0, hp_npos = 0;  // allocated elements
   hipEvent_t hp_ev_h2d = nullptr;     // "the block's inputs have arrived": the lane's streams wait for it
   BlockResult *hp_result = nullptr;   // page-locked landing place of the result block
+  ParseScratch hp_parse;              // fqgpu_encode_begin without a record table: the table is built on the device
+  bool hp_pending = false;            // a block of fqgpu_encode_begin is in flight (fqgpu_encode_end collects it)
+  unsigned hp_flags = 0;
+  hipStream_t hp_done = nullptr;      // the stream its last kernel runs on
 };
 
 EncLane *fq_next_lane(fqgpu_ctx *ctx);  // api.hip: round-robin, creates streams on first use
@@ -231,6 +241,9 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
 int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered);
 int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks);
 int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);
+int fq_parse_count(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, ParseScratch &ps, size_t *n_recs);
+int fq_parse_records(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, ParseScratch &ps, fqgpu_rec *recs_dev,
+                     size_t n_recs, size_t *n_bases, size_t *n_n, size_t *used_len);
 
 // generic exclusive scans (scan.hip): out has n+1 entries, out[n] = total
 int fq_scan_u32_to_u32(hipStream_t st, const uint32_t *in, size_t n, uint32_t *out, DevBuf &tmp);

@@ -10,6 +10,8 @@
 // A trailing partial record is ignored, like the reference's carry-over to the next chunk.
 #include "fqgpu_internal.h"
 
+#include <utility>
+
 namespace {
 
 constexpr unsigned PCHUNK = 4096;  // bytes per workgroup: 256 threads x 16 bytes
@@ -69,6 +71,7 @@ k_nl_write(const uint8_t *__restrict__ raw, size_t len, const uint32_t *__restri
 
 struct ParseSummary {
   unsigned long long n_bases, n_n;
+  unsigned long long used_len;  // bytes up to and including the last complete record
   unsigned int bad_format;   // line 1 not '@', line 3 not '+', seq/qual length mismatch
   unsigned int short_read;   // a read shorter than 3
   unsigned int too_long;     // a read longer than 65535 (readlen_t)
@@ -91,6 +94,7 @@ k_records(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ nl_pos, 
     recs[r].qual_off = l3;
     recs[r].len = len;
     bases = len;
+    if (r == n_recs - 1) sum->used_len = (unsigned long long)e3 + 1ull;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) bases += __shfl_xor(bases, d);
@@ -116,54 +120,67 @@ k_count_n(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, u
 
 }  // namespace
 
-// raw_dev: device copy of the block, padded by >= 64 readable bytes.  On success *recs_dev is a
-// hipMalloc'ed record table the caller owns.
+// raw_dev: device copy of the block, padded by >= 64 readable bytes.  Two steps, because the record
+// table can only be sized once the lines are counted; both wait for st (a few bytes come back).
+// The scratch is the caller's and only grows: a worker that parses chunk after chunk allocates
+// nothing (hipFree waits for the device to be idle).
+int fq_parse_count(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, ParseScratch &ps, size_t *n_recs) {
+  *n_recs = 0;
+  if (raw_len == 0 || raw_len >= 0xFFF00000ull) return FQGPU_E_ARG;
+  const size_t n_chunks = (raw_len + PCHUNK - 1) / PCHUNK;
+  int rc;
+  if ((rc = ps.cnt.reserve(n_chunks * 4)) || (rc = ps.base.reserve((n_chunks + 1) * 4)) || (rc = ps.sum.reserve(sizeof(ParseSummary)))) return rc;
+  hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_chunks), dim3(256), 0, st, raw_dev, raw_len, ps.cnt.as<uint32_t>());
+  if ((rc = fq_scan_u32_to_u32(st, ps.cnt.as<uint32_t>(), n_chunks, ps.base.as<uint32_t>(), ps.scan_tmp))) return rc;
+  uint32_t total_nl = 0;
+  FQ_HIP(hipMemcpyAsync(&total_nl, ps.base.as<uint32_t>() + n_chunks, 4, hipMemcpyDeviceToHost, st));
+  FQ_HIP(hipStreamSynchronize(st));
+  ps.total_nl = total_nl;
+  *n_recs = total_nl / 4;  // a trailing partial record is ignored
+  return *n_recs ? FQGPU_OK : FQGPU_E_ARG;
+}
+
+int fq_parse_records(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, ParseScratch &ps, fqgpu_rec *recs_dev,
+                     size_t n_recs, size_t *n_bases, size_t *n_n, size_t *used_len) {
+  const size_t n_chunks = (raw_len + PCHUNK - 1) / PCHUNK;
+  int rc;
+  if ((rc = ps.nl_pos.reserve(((size_t)ps.total_nl + 4) * 4))) return rc;
+  ParseSummary *sum = ps.sum.as<ParseSummary>();
+  FQ_HIP(hipMemsetAsync(sum, 0, sizeof(ParseSummary), st));
+  hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_chunks), dim3(256), 0, st, raw_dev, raw_len, ps.base.as<uint32_t>(), ps.nl_pos.as<uint32_t>());
+  hipLaunchKernelGGL(k_records, dim3((unsigned)((n_recs + 255) / 256)), dim3(256), 0, st, raw_dev, ps.nl_pos.as<uint32_t>(),
+                     (unsigned)n_recs, recs_dev, sum);
+  const unsigned nb = (unsigned)min((n_recs + 3) / 4, (size_t)8192);
+  hipLaunchKernelGGL(k_count_n, dim3(nb), dim3(256), 0, st, raw_dev, recs_dev, (unsigned)n_recs, sum);
+  ParseSummary h;
+  FQ_HIP(hipMemcpyAsync(&h, sum, sizeof(h), hipMemcpyDeviceToHost, st));
+  FQ_HIP(hipStreamSynchronize(st));
+  if (h.bad_format || h.too_long) return FQGPU_E_ARG;
+  if (h.short_read) return FQGPU_E_SHORT_READ;
+  if (h.n_bases >= 0xFFF00000ull) return FQGPU_E_ARG;
+  *n_bases = (size_t)h.n_bases;
+  *n_n = (size_t)h.n_n;
+  if (used_len) *used_len = (size_t)h.used_len;
+  return FQGPU_OK;
+}
+
+// the two steps with a record table allocated here; on success *recs_dev is hipMalloc'ed and the caller's
 int fq_parse_on_device(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, DevBuf &scan_tmp,
                        fqgpu_rec **recs_dev, size_t *n_recs, size_t *n_bases, size_t *n_n) {
   *recs_dev = nullptr;
   *n_recs = *n_bases = *n_n = 0;
-  if (raw_len == 0 || raw_len >= 0xFFF00000ull) return FQGPU_E_ARG;
-  const size_t n_chunks = (raw_len + PCHUNK - 1) / PCHUNK;
-  uint32_t *cnt = fq_dev_alloc<uint32_t>(n_chunks);
-  uint32_t *base = fq_dev_alloc<uint32_t>(n_chunks + 1);
-  ParseSummary *sum = fq_dev_alloc<ParseSummary>(1);
-  uint32_t *nl_pos = nullptr;
+  ParseScratch ps;
+  std::swap(ps.scan_tmp, scan_tmp);
+  size_t R = 0;
+  int rc = fq_parse_count(st, raw_dev, raw_len, ps, &R);
   fqgpu_rec *recs = nullptr;
-  int rc = FQGPU_OK;
-  do {
-    if (!cnt || !base || !sum) { rc = FQGPU_E_NOMEM; break; }
-    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_chunks), dim3(256), 0, st, raw_dev, raw_len, cnt);
-    if ((rc = fq_scan_u32_to_u32(st, cnt, n_chunks, base, scan_tmp))) break;
-    uint32_t total_nl = 0;
-    if (hipMemcpyAsync(&total_nl, base + n_chunks, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) { rc = FQGPU_E_HIP; break; }
-    const size_t R = total_nl / 4;  // a trailing partial record is ignored
-    if (R == 0) { rc = FQGPU_E_ARG; break; }
-    nl_pos = fq_dev_alloc<uint32_t>((size_t)total_nl + 4);
-    recs = fq_dev_alloc<fqgpu_rec>(R);
-    if (!nl_pos || !recs) { rc = FQGPU_E_NOMEM; break; }
-    if (hipMemsetAsync(sum, 0, sizeof(ParseSummary), st) != hipSuccess) { rc = FQGPU_E_HIP; break; }
-    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_chunks), dim3(256), 0, st, raw_dev, raw_len, base, nl_pos);
-    hipLaunchKernelGGL(k_records, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, raw_dev, nl_pos,
-                       (unsigned)R, recs, sum);
-    const unsigned nb = (unsigned)min((R + 3) / 4, (size_t)8192);
-    hipLaunchKernelGGL(k_count_n, dim3(nb), dim3(256), 0, st, raw_dev, recs, (unsigned)R, sum);
-    ParseSummary h;
-    if (hipMemcpyAsync(&h, sum, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) { rc = FQGPU_E_HIP; break; }
-    if (h.bad_format || h.too_long) { rc = FQGPU_E_ARG; break; }
-    if (h.short_read) { rc = FQGPU_E_SHORT_READ; break; }
-    if (h.n_bases >= 0xFFF00000ull) { rc = FQGPU_E_ARG; break; }
-    *recs_dev = recs;
-    recs = nullptr;
-    *n_recs = R;
-    *n_bases = (size_t)h.n_bases;
-    *n_n = (size_t)h.n_n;
-  } while (0);
-  if (cnt) (void)hipFree(cnt);
-  if (base) (void)hipFree(base);
-  if (sum) (void)hipFree(sum);
-  if (nl_pos) (void)hipFree(nl_pos);
-  if (recs) (void)hipFree(recs);
-  return rc;
+  if (!rc && !(recs = fq_dev_alloc<fqgpu_rec>(R))) rc = FQGPU_E_NOMEM;
+  if (!rc) rc = fq_parse_records(st, raw_dev, raw_len, ps, recs, R, n_bases, n_n, nullptr);
+  std::swap(ps.scan_tmp, scan_tmp);
+  DevBuf *bufs[] = {&ps.cnt, &ps.base, &ps.sum, &ps.nl_pos};
+  for (DevBuf *b : bufs) b->release();
+  if (rc) { if (recs) (void)hipFree(recs); return rc; }
+  *recs_dev = recs;
+  *n_recs = R;
+  return FQGPU_OK;
 }

@@ -1,8 +1,9 @@
 // process.hpp -- the reference's block pipeline (src/process.cpp:32-105) over the GPU workspaces:
 // N worker threads, each owning chunk + buffers + workspace (src/process.cpp:49-54, 95-98), pull
-// whole blocks from a mutex-protected reader, code them, and hand them to a mutex-protected
-// writer; blocks land in the archive in COMPLETION order and the index records chunk_idx
-// (src/archive.cpp:57-106, src/archive.h:85-89).
+// whole blocks from a reader, code them, and hand them to a writer; blocks land in the archive in
+// the order they claim their space and the index records chunk_idx (src/archive.h:85-89).  Reader,
+// archive and writer (archive.hpp) move the bytes OUTSIDE their locks, and a failing worker stops
+// the farm instead of leaving the others waiting (the reference's ordered writer would wait forever).
 //
 // What is new against the reference is only where a worker's workspace lives: worker t of T uses
 // GPU devices[t mod G] (blocks are independent given the tables, every GPU holds a
@@ -55,24 +56,28 @@ inline std::size_t miscBytes(const CompressedBuffersDst &cbs) {
   for (const auto &f : cbs.compressed_header_fields) n += f.isDifferentFlag.size() + f.content.size() + f.contentLength.size();
   return n;
 }
-/** runs body(t) on n threads; the first exception of any worker is rethrown after all have joined */
-template <class Body> void runWorkers(unsigned n, Body &&body) {
+/** runs body(t) on n threads; a worker that throws calls on_failure() (which must make the sources
+ *  of work run dry, so that the others finish their block and stop: nobody waits for anybody here);
+ *  the first exception is rethrown after all have joined */
+template <class Body, class OnFailure> void runWorkers(unsigned n, Body &&body, OnFailure &&on_failure) {
   std::vector<std::thread> threads;
   std::vector<std::exception_ptr> errors(n);
   threads.reserve(n);
   for (unsigned t = 0; t < n; ++t)
     threads.emplace_back([&, t] {
-      try { body(t); } catch (...) { errors[t] = std::current_exception(); }
+      try { body(t); } catch (...) { errors[t] = std::current_exception(); on_failure(); }
     });
   for (auto &th : threads) th.join();
   for (auto &e : errors) if (e) std::rethrow_exception(e);
 }
+template <class Body> void runWorkers(unsigned n, Body &&body) { runWorkers(n, body, [] {}); }
 }  // namespace detail
 
 /** The compression farm: `next_chunk(chunk)` and `write_block(cbs)` are called concurrently from
- *  the workers and must be thread-safe (FastqReader::readNextChunk and Archive::writeBlock are). */
-template <class Source, class Sink>
-FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&write_block, const Settings &set) {
+ *  the workers and must be thread-safe (FastqReader::readNextChunk and Archive::writeBlock are);
+ *  `stop()` is called when a worker fails and must make next_chunk return false from then on. */
+template <class Source, class Sink, class Stop>
+FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&write_block, Stop &&stop, const Settings &set) {
   const unsigned T = std::max(1u, set.n_threads);
   if (set.devices.empty()) throw std::invalid_argument("compressFarm: no device");
   // every worker builds its workspace first (256 + 8192 tables on its GPU: the reference does the
@@ -88,12 +93,12 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
     FastqChunk chunk;
     CompressedBuffersDst cbs;
     while (next_chunk(chunk)) {
+      if (!set.accumulate_n_buffers) { cbs.n_count.clear(); cbs.n_pos.clear(); }
+      wksp[t]->encodeChunk(chunk, cbs);  // (an unparsed chunk has its records found on the GPU: the sums are known afterwards)
       istats[t].seq += chunk.tot_reads_length;
       istats[t].header += chunk.headers_length;
       istats[t].n_records += chunk.records.size();
       istats[t].raw += chunk.raw_data.size();
-      if (!set.accumulate_n_buffers) { cbs.n_count.clear(); cbs.n_pos.clear(); }
-      wksp[t]->encodeChunk(chunk, cbs);
       cstats[t].seq += cbs.seq.size();
       cstats[t].qual += cbs.qual.size();
       cstats[t].misc += detail::miscBytes(cbs);
@@ -101,27 +106,33 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
       rep.blocks_per_worker[t]++;
       write_block(cbs);
     }
-  });
+  }, stop);
   rep.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   for (unsigned t = 0; t < T; ++t) { rep.in += istats[t]; rep.out += cstats[t]; }
   return rep;
+}
+template <class Source, class Sink>
+FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&write_block, const Settings &set) {
+  std::atomic<bool> stopped{false};
+  return compressFarm(meta, [&](FastqChunk &c) { return !stopped.load() && next_chunk(c); }, write_block, [&] { stopped.store(true); }, set);
 }
 
 /** processReads (src/process.cpp:32-82): file in, archive out */
 inline FarmReport processReads(const path_t &mates1, const path_t &archive_path, const Settings &set) {
   Archive archive(archive_path, mates1, set.sample_chunk_size, set.devices.at(0));
-  FastqReader reader(mates1.string(), set.reading_chunk_size);
+  FastqReader reader(mates1, set.reading_chunk_size);
   FarmReport rep = compressFarm(
       archive.meta(), [&](FastqChunk &c) { return reader.readNextChunk(c); },
-      [&](const CompressedBuffersDst &cbs) { archive.writeBlock(cbs); }, set);
+      [&](const CompressedBuffersDst &cbs) { archive.writeBlock(cbs); }, [&] { reader.abort(); }, set);
   archive.writeIndex();
   archive.flush();
   return rep;
 }
 
-/** The decompression farm (src/process.cpp:84-105): `next_block(cbs)` / `write_chunk(chunk)` thread-safe */
-template <class Source, class Sink>
-FarmReport decompressFarm(const DatasetMeta &meta, Source &&next_block, Sink &&write_chunk, const Settings &set) {
+/** The decompression farm (src/process.cpp:84-105): `next_block(cbs)` / `write_chunk(chunk)` thread-safe;
+ *  `stop()`: a worker has failed, next_block must return false from now on */
+template <class Source, class Sink, class Stop>
+FarmReport decompressFarm(const DatasetMeta &meta, Source &&next_block, Sink &&write_chunk, Stop &&stop, const Settings &set) {
   const unsigned T = std::max(1u, set.n_threads);
   if (set.devices.empty()) throw std::invalid_argument("decompressFarm: no device");
   std::vector<std::unique_ptr<DecompressionWorkspace>> wksp(T);
@@ -140,19 +151,24 @@ FarmReport decompressFarm(const DatasetMeta &meta, Source &&next_block, Sink &&w
       rep.blocks_per_worker[t]++;
       write_chunk(chunk);
     }
-  });
+  }, stop);
   rep.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   for (unsigned t = 0; t < T; ++t) rep.in += istats[t];
   return rep;
+}
+template <class Source, class Sink>
+FarmReport decompressFarm(const DatasetMeta &meta, Source &&next_block, Sink &&write_chunk, const Settings &set) {
+  std::atomic<bool> stopped{false};
+  return decompressFarm(meta, [&](CompressedBuffersSrc &c) { return !stopped.load() && next_block(c); }, write_chunk, [&] { stopped.store(true); }, set);
 }
 
 /** processArchiveParts (src/process.cpp:84-105): archive in, file out (chunks in original order) */
 inline FarmReport processArchiveParts(const path_t &archive_path, const path_t &mates1_out, const Settings &set) {
   Archive archive(archive_path);
-  FastqWriter writer(mates1_out.string());
+  FastqWriter writer(mates1_out, archive.chunkOffsets());
   FarmReport rep = decompressFarm(
       archive.meta(), [&](CompressedBuffersSrc &cbs) { return archive.readBlock(cbs); },
-      [&](const FastqChunk &chunk) { writer.writeChunk(chunk); }, set);
+      [&](const FastqChunk &chunk) { writer.writeChunk(chunk); }, [&] { archive.abort(); }, set);
   writer.flush();
   return rep;
 }

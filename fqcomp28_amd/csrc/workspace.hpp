@@ -124,6 +124,26 @@ inline std::size_t memdecompress(std::byte *dst, std::size_t dst_size, const std
   if (n == static_cast<std::size_t>(-1) || (src_size && n != dst_size)) throw std::runtime_error("memdecompress: malformed misc stream");
   return n;
 }
+/** Every misc stream of a block (everything but the two FSE streams) as f(plain, compressed,
+ *  original size): the one list both directions of the misc pass walk (reference
+ *  src/workspace.cpp:176-256 runs libbsc over the same streams).  A NUMERIC header field has a
+ *  content stream only. */
+template <class Buffers, class F> void miscStreams(Buffers &cbs, const headers::HeaderFormatSpeciciation &fmt, F &&f) {
+  f(cbs.readlens, cbs.compressed_readlens, cbs.original_size.readlens);
+  f(cbs.n_count, cbs.compressed_n_count, cbs.original_size.n_count);
+  f(cbs.n_pos, cbs.compressed_n_pos, cbs.original_size.n_pos);
+  for (std::size_t i = 0; i < fmt.n_fields(); ++i) {
+    auto &plain = cbs.header_fields[i];
+    auto &packed = cbs.compressed_header_fields[i];
+    auto &sizes = cbs.original_size.header_fields[i];
+    f(plain.content, packed.content, sizes.content);
+    if (fmt.field_types[i] == headers::FieldType::STRING) {
+      f(plain.isDifferentFlag, packed.isDifferentFlag, sizes.isDifferentFlag);
+      f(plain.contentLength, packed.contentLength, sizes.contentLength);
+    }
+  }
+}
+
 struct CompressedBuffersDst : CompressedBuffers {
   std::vector<headers::FieldStorageDst> header_fields;
   void clear() override {
@@ -168,27 +188,44 @@ struct DatasetMeta {
   /** bytes of the metadata section of an archive (src/prepare.h:44-52) */
   [[nodiscard]] std::size_t size() const { return sizeof(readlen_t) + first_header.length() + FQGPU_SEQ_FT_BYTES + FQGPU_QUAL_FT_BYTES; }
 
-  /** DatasetMeta::storeToStream (src/prepare.cpp:12-21), byte for byte: u16 header length, the
-   *  header, then the two FreqTable PODs as they lie in memory */
-  static void storeToStream(const DatasetMeta &meta, std::ostream &os) {
-    if (meta.first_header.size() > 0xFFFFu) throw std::invalid_argument("first header longer than a readlen_t");
-    const readlen_t hlen = static_cast<readlen_t>(meta.first_header.size());
-    os.write(reinterpret_cast<const char *>(&hlen), sizeof(hlen));
-    os.write(meta.first_header.data(), hlen);
-    os.write(reinterpret_cast<const char *>(meta.ft_seq.get()), FQGPU_SEQ_FT_BYTES);
-    os.write(reinterpret_cast<const char *>(meta.ft_qual.get()), FQGPU_QUAL_FT_BYTES);
+  /** The metadata section of an archive (src/prepare.cpp:12-21 writes the same bytes): u16 header
+   *  length, the header, then the two FreqTable PODs as they lie in memory */
+  void appendTo(std::vector<uint8_t> &out) const {
+    if (first_header.size() > 0xFFFFu) throw std::invalid_argument("first header longer than a readlen_t");
+    const readlen_t hlen = static_cast<readlen_t>(first_header.size());
+    const std::size_t at = out.size();
+    out.resize(at + size());
+    uint8_t *p = out.data() + at;
+    std::memcpy(p, &hlen, sizeof(hlen));
+    std::memcpy(p + sizeof(hlen), first_header.data(), hlen);
+    std::memcpy(p + sizeof(hlen) + hlen, ft_seq.get(), FQGPU_SEQ_FT_BYTES);
+    std::memcpy(p + sizeof(hlen) + hlen + FQGPU_SEQ_FT_BYTES, ft_qual.get(), FQGPU_QUAL_FT_BYTES);
   }
-  /** DatasetMeta::loadFromStream (src/prepare.cpp:23-41) */
-  static DatasetMeta loadFromStream(std::istream &is) {
+  static DatasetMeta fromBytes(const uint8_t *p, std::size_t n) {
     readlen_t hlen = 0;
-    is.read(reinterpret_cast<char *>(&hlen), sizeof(hlen));
-    std::string header(hlen, '!');
-    is.read(header.data(), hlen);
-    DatasetMeta meta{std::string_view(header)};
-    is.read(reinterpret_cast<char *>(meta.ft_seq.get()), FQGPU_SEQ_FT_BYTES);
-    is.read(reinterpret_cast<char *>(meta.ft_qual.get()), FQGPU_QUAL_FT_BYTES);
-    if (!is.good()) throw std::runtime_error("truncated dataset metadata");
+    if (n < sizeof(hlen)) throw std::runtime_error("truncated dataset metadata");
+    std::memcpy(&hlen, p, sizeof(hlen));
+    if (n < sizeof(hlen) + hlen + FQGPU_SEQ_FT_BYTES + FQGPU_QUAL_FT_BYTES) throw std::runtime_error("truncated dataset metadata");
+    DatasetMeta meta{std::string_view(reinterpret_cast<const char *>(p) + sizeof(hlen), hlen)};
+    std::memcpy(meta.ft_seq.get(), p + sizeof(hlen) + hlen, FQGPU_SEQ_FT_BYTES);
+    std::memcpy(meta.ft_qual.get(), p + sizeof(hlen) + hlen + FQGPU_SEQ_FT_BYTES, FQGPU_QUAL_FT_BYTES);
     return meta;
+  }
+  /** the same through streams, under the reference's names (src/prepare.cpp:12-41) */
+  static void storeToStream(const DatasetMeta &meta, std::ostream &os) {
+    std::vector<uint8_t> bytes;
+    meta.appendTo(bytes);
+    os.write(reinterpret_cast<const char *>(bytes.data()), static_cast<std::streamsize>(bytes.size()));
+  }
+  static DatasetMeta loadFromStream(std::istream &is) {
+    std::vector<uint8_t> bytes(sizeof(readlen_t));
+    is.read(reinterpret_cast<char *>(bytes.data()), sizeof(readlen_t));
+    readlen_t hlen = 0;
+    std::memcpy(&hlen, bytes.data(), sizeof(hlen));
+    bytes.resize(sizeof(hlen) + hlen + FQGPU_SEQ_FT_BYTES + FQGPU_QUAL_FT_BYTES);
+    is.read(reinterpret_cast<char *>(bytes.data()) + sizeof(hlen), static_cast<std::streamsize>(bytes.size() - sizeof(hlen)));
+    if (!is.good()) throw std::runtime_error("truncated dataset metadata");
+    return fromBytes(bytes.data(), bytes.size());
   }
   friend bool operator==(const DatasetMeta &a, const DatasetMeta &b) {
     return a.first_header == b.first_header && std::memcmp(a.ft_seq.get(), b.ft_seq.get(), FQGPU_SEQ_FT_BYTES) == 0 &&
@@ -232,87 +269,87 @@ class CompressionWorkspace : public Workspace {
 public:
   explicit CompressionWorkspace(const DatasetMeta *meta, int device = 0) : Workspace(meta, device) {}
 
-  /** Encodes reads into cbs, allocating memory in cbs as needed; mutates the chunk (N -> A) */
+  /** Encodes reads into cbs, allocating memory in cbs as needed; mutates the chunk (N -> A).
+   *  The chunk may come UNPARSED (records empty, as FastqReader hands it out): the GPU then finds the
+   *  records, and chunk.records / the length sums are filled in from its table.  The GPU work is
+   *  started first; the headers are coded on this thread while it runs. */
   void encodeChunk(FastqChunk &chunk, CompressedBuffersDst &cbs) {
     cbs.clear();
     cbs.chunk_idx = chunk.idx;
-    const std::size_t R = chunk.records.size();
-    cbs.seq.resize(compressBoundSequence(chunk.tot_reads_length));
-    cbs.qual.resize(compressBoundQuality(chunk.tot_reads_length));
-    cbs.readlens.resize(R * sizeof(readlen_t));
+    auto *raw = reinterpret_cast<uint8_t *>(chunk.raw_data.data());
+    const bool parsed = !chunk.records.empty();
+    RecordTable recs;
+    if (parsed) recs = DatasetMeta::toRecordTable(chunk);
+    std::size_t R = 0, n_bases = 0, used = 0;
+    fqgpuCheck(fqgpu_encode_begin(ctx_, raw, chunk.raw_data.size(), parsed ? recs.data() : nullptr, recs.size(),
+                                  FQGPU_F_WRITE_BACK_N, &R, &n_bases, &used),
+               "encodeChunk");
+    if (!parsed) {
+      recs.resize(R);
+      fqgpuCheck(fqgpu_encode_records(ctx_, recs.data(), R), "encodeChunk");
+      if (used != chunk.raw_data.size()) throw std::invalid_argument("encodeChunk: the chunk does not end with a complete record");
+      recordViews(chunk, recs);
+    }
+    // ---- host work in the shadow of the GPU: the header fields
     cbs.header_fields.resize(fmt_.n_fields());
     cbs.original_size.header_fields.resize(fmt_.n_fields());
     for (auto &field : cbs.header_fields) field.clear();
     startNewChunk();
     for (const FastqRecord &r : chunk.records) headers::encodeHeader(r.header(), fmt_, prev_header_fields_, cbs.header_fields);
-    for (std::size_t i = 0; i < fmt_.n_fields(); ++i) cbs.original_size.header_fields[i] = cbs.header_fields[i].originalSizes();
-    RecordTable recs = DatasetMeta::toRecordTable(chunk);
-    u16_buffer_t n_count(R), n_pos(chunk.tot_reads_length);
+    // ---- the streams, at their exact sizes
     std::size_t seq_len = 0, qual_len = 0, n_pos_len = 0;
-    fqgpuCheck(fqgpu_encode_block(ctx_, reinterpret_cast<uint8_t *>(chunk.raw_data.data()),
-                                  chunk.raw_data.size(), recs.data(), R,
-                                  reinterpret_cast<uint8_t *>(cbs.seq.data()), cbs.seq.size(), &seq_len,
-                                  reinterpret_cast<uint8_t *>(cbs.qual.data()), cbs.qual.size(), &qual_len,
-                                  reinterpret_cast<uint16_t *>(cbs.readlens.data()), n_count.data(),
-                                  n_pos.data(), n_pos.size(), &n_pos_len, FQGPU_F_WRITE_BACK_N),
-               "encodeChunk");
+    fqgpuCheck(fqgpu_encode_wait(ctx_, &seq_len, &qual_len, &n_pos_len), "encodeChunk");
     cbs.seq.resize(seq_len);
     cbs.qual.resize(qual_len);
-    // appended, never cleared: what a reused CompressedBuffersDst holds in the reference
-    append(cbs.n_count, n_count.data(), R);
-    append(cbs.n_pos, n_pos.data(), n_pos_len);
+    cbs.readlens.resize(R * sizeof(readlen_t));
+    // n_count / n_pos are appended, never cleared: what a reused CompressedBuffersDst holds in the reference
+    const std::size_t cnt_at = cbs.n_count.size(), pos_at = cbs.n_pos.size();
+    cbs.n_count.resize(cnt_at + R * sizeof(uint16_t));
+    cbs.n_pos.resize(pos_at + n_pos_len * sizeof(uint16_t));
+    fqgpuCheck(fqgpu_encode_end(ctx_, raw, reinterpret_cast<uint8_t *>(cbs.seq.data()), cbs.seq.size(), &seq_len,
+                                reinterpret_cast<uint8_t *>(cbs.qual.data()), cbs.qual.size(), &qual_len,
+                                reinterpret_cast<uint16_t *>(cbs.readlens.data()), reinterpret_cast<uint16_t *>(cbs.n_count.data() + cnt_at),
+                                reinterpret_cast<uint16_t *>(cbs.n_pos.data() + pos_at), n_pos_len, &n_pos_len),
+               "encodeChunk");
     cbs.original_size.n_records = static_cast<uint32_t>(R);
     cbs.original_size.total = static_cast<uint32_t>(chunk.raw_data.size());
-    cbs.original_size.readlens = static_cast<uint32_t>(cbs.readlens.size());
-    cbs.original_size.n_count = static_cast<uint32_t>(cbs.n_count.size());
-    cbs.original_size.n_pos = static_cast<uint32_t>(cbs.n_pos.size());
     compressMiscBuffers(cbs);
   }
 
-  /** CompressionWorkspace::compressMiscBuffers (src/workspace.cpp:176-213): readlens, n_count, n_pos
-   *  and every header field stream through memcompress; original sizes recorded for the container */
+  /** The misc pass (the reference's compressMiscBuffers, src/workspace.cpp:176-213): readlens, n_count,
+   *  n_pos and every header field stream through memcompress, original sizes recorded for the container */
   void compressMiscBuffers(CompressedBuffersDst &cbs) const { compressMiscBuffers(cbs, fmt_); }
   /** the same without a workspace (host-only tools and tests: no GPU involved) */
-  static void compressMiscBuffers(CompressedBuffersDst &cbs, const headers::HeaderFormatSpeciciation &fmt_) {
-    cbs.original_size.readlens = static_cast<uint32_t>(cbs.readlens.size());
-    compressBuffer(cbs.compressed_readlens, cbs.readlens);
-    cbs.original_size.n_count = static_cast<uint32_t>(cbs.n_count.size());
-    compressBuffer(cbs.compressed_n_count, cbs.n_count);
-    cbs.original_size.n_pos = static_cast<uint32_t>(cbs.n_pos.size());
-    compressBuffer(cbs.compressed_n_pos, cbs.n_pos);
-    cbs.compressed_header_fields.resize(fmt_.n_fields());
-    cbs.original_size.header_fields.resize(fmt_.n_fields());
-    for (std::size_t i = 0, E = fmt_.n_fields(); i < E; ++i) {
-      const auto &field_data = cbs.header_fields[i];
-      auto &field_cdata = cbs.compressed_header_fields[i];
-      auto &original_size = cbs.original_size.header_fields[i];
-      if (fmt_.field_types[i] == headers::FieldType::STRING) {
-        compressBuffer(field_cdata.isDifferentFlag, field_data.isDifferentFlag);
-        compressBuffer(field_cdata.content, field_data.content);
-        compressBuffer(field_cdata.contentLength, field_data.contentLength);
-        original_size = field_data.originalSizes();
-      } else { /* NUMERIC */
-        compressBuffer(field_cdata.content, field_data.content);
-        field_cdata.isDifferentFlag.clear(); field_cdata.contentLength.clear();
-        original_size = {};
-        original_size.content = static_cast<uint32_t>(field_data.content.size());
-      }
+  static void compressMiscBuffers(CompressedBuffersDst &cbs, const headers::HeaderFormatSpeciciation &fmt) {
+    cbs.compressed_header_fields.resize(fmt.n_fields());
+    cbs.original_size.header_fields.assign(fmt.n_fields(), {});
+    for (auto &packed : cbs.compressed_header_fields) packed.clear();
+    miscStreams(cbs, fmt, [](const auto &plain, std::vector<std::byte> &packed, uint32_t &size) {
+      size = static_cast<uint32_t>(plain.size());
+      packed.resize(fqgpu_memcompress_bound(plain.size()));
+      packed.resize(memcompress(packed.data(), plain.data(), plain.size()));
+    });
+  }
+
+  /** chunk.records (pointers into the chunk) and the length sums from a record table */
+  static void recordViews(FastqChunk &chunk, const RecordTable &recs) {
+    chunk.records.resize(recs.size());
+    chunk.tot_reads_length = chunk.headers_length = 0;
+    char *base = chunk.raw_data.data();
+    std::size_t line = 0;  // start of the record's header line
+    for (std::size_t i = 0; i < recs.size(); ++i) {
+      FastqRecord &r = chunk.records[i];
+      r.headerp = base + line;
+      r.header_length = static_cast<readlen_t>(recs[i].seq_off - 1 - line);
+      r.seqp = base + recs[i].seq_off;
+      r.qualp = base + recs[i].qual_off;
+      r.length = static_cast<readlen_t>(recs[i].len);
+      chunk.tot_reads_length += r.length;
+      chunk.headers_length += r.header_length;
+      line = static_cast<std::size_t>(recs[i].qual_off) + recs[i].len + 1;
     }
   }
 
-private:
-  /** compressBuffer (src/workspace.cpp:258-265) */
-  template <class Bytes> static std::size_t compressBuffer(std::vector<std::byte> &dst, const Bytes &src) {
-    dst.resize(fqgpu_memcompress_bound(src.size()));
-    const std::size_t csize = memcompress(dst.data(), src.data(), src.size());
-    dst.resize(csize);
-    return csize;
-  }
-  template <class Bytes> static void append(Bytes &dst, const uint16_t *src, std::size_t n) {
-    const std::size_t old = dst.size();
-    dst.resize(old + n * sizeof(uint16_t));
-    std::memcpy(dst.data() + old, src, n * sizeof(uint16_t));
-  }
 };
 
 class DecompressionWorkspace : public Workspace {
@@ -358,36 +395,21 @@ public:
                "decodeChunk");
   }
 
-  /** DecompressionWorkspace::decompressMiscBuffers (src/workspace.cpp:215-256): every misc stream
-   *  is restored from its compressed twin to the size the container recorded; index.n_count /
+  /** The misc pass backwards (the reference's decompressMiscBuffers, src/workspace.cpp:215-256): every
+   *  misc stream is restored from its compressed twin to the size the container recorded; index.n_count /
    *  index.n_pos are set to the ends of the buffers (the decoder pops from there) */
   void decompressMiscBuffers(CompressedBuffersSrc &cbs) const { decompressMiscBuffers(cbs, fmt_); }
-  static void decompressMiscBuffers(CompressedBuffersSrc &cbs, const headers::HeaderFormatSpeciciation &fmt_) {
-    cbs.readlens.resize(cbs.original_size.readlens);
-    memdecompress(cbs.readlens.data(), cbs.readlens.size(), cbs.compressed_readlens.data(), cbs.compressed_readlens.size());
-    cbs.index.n_count = cbs.original_size.n_count;
-    cbs.n_count.resize(cbs.original_size.n_count);
-    memdecompress(cbs.n_count.data(), cbs.n_count.size(), cbs.compressed_n_count.data(), cbs.compressed_n_count.size());
-    cbs.index.n_pos = cbs.original_size.n_pos;
-    cbs.n_pos.resize(cbs.original_size.n_pos);
-    memdecompress(cbs.n_pos.data(), cbs.n_pos.size(), cbs.compressed_n_pos.data(), cbs.compressed_n_pos.size());
-    if (cbs.compressed_header_fields.size() != fmt_.n_fields() || cbs.original_size.header_fields.size() != fmt_.n_fields())
+  static void decompressMiscBuffers(CompressedBuffersSrc &cbs, const headers::HeaderFormatSpeciciation &fmt) {
+    if (cbs.compressed_header_fields.size() != fmt.n_fields() || cbs.original_size.header_fields.size() != fmt.n_fields())
       throw std::invalid_argument("decodeChunk: header field streams do not match the format");
-    cbs.header_fields.resize(fmt_.n_fields());
-    for (std::size_t i = 0, E = fmt_.n_fields(); i < E; ++i) {
-      const auto &field_cdata = cbs.compressed_header_fields[i];
-      const auto &original_size = cbs.original_size.header_fields[i];
-      auto &field_data = cbs.header_fields[i];
-      field_data.clear();
-      field_data.content.resize(original_size.content);
-      memdecompress(field_data.content.data(), field_data.content.size(), field_cdata.content.data(), field_cdata.content.size());
-      if (fmt_.field_types[i] == headers::FieldType::STRING) {
-        field_data.isDifferentFlag.resize(original_size.isDifferentFlag);
-        field_data.contentLength.resize(original_size.contentLength);
-        memdecompress(field_data.isDifferentFlag.data(), field_data.isDifferentFlag.size(), field_cdata.isDifferentFlag.data(), field_cdata.isDifferentFlag.size());
-        memdecompress(field_data.contentLength.data(), field_data.contentLength.size(), field_cdata.contentLength.data(), field_cdata.contentLength.size());
-      }
-    }
+    cbs.header_fields.resize(fmt.n_fields());
+    for (auto &plain : cbs.header_fields) plain.clear();
+    miscStreams(cbs, fmt, [](auto &plain, const std::vector<std::byte> &packed, const uint32_t &size) {
+      plain.resize(size);
+      memdecompress(plain.data(), plain.size(), packed.data(), packed.size());
+    });
+    cbs.index.n_count = cbs.n_count.size();
+    cbs.index.n_pos = cbs.n_pos.size();
   }
 
 private:
@@ -409,28 +431,16 @@ private:
   std::vector<char> tail_;
 };
 
-/** FastqReader::parseRecords (src/fastq_io.cpp:67-125) on top of fqgpu_parse_fastq */
+/** The host parser (FastqReader::parseRecords, src/fastq_io.cpp:67-125) on top of fqgpu_parse_fastq: fills
+ *  chunk.records; returns the bytes up to the end of the last complete record */
 inline std::size_t parseRecords(FastqChunk &chunk) {
   const auto *raw = reinterpret_cast<const uint8_t *>(chunk.raw_data.data());
   const long n = fqgpu_parse_fastq(raw, chunk.raw_data.size(), nullptr, 0);
   if (n < 0) throw std::invalid_argument("malformed FASTQ block");
-  std::vector<fqgpu_rec> recs(static_cast<std::size_t>(n));
+  RecordTable recs(static_cast<std::size_t>(n));
   fqgpu_parse_fastq(raw, chunk.raw_data.size(), recs.data(), recs.size());
-  chunk.records.resize(recs.size());
-  char *base = chunk.raw_data.data();
-  std::size_t prev_end = 0;
-  for (std::size_t i = 0; i < recs.size(); ++i) {
-    FastqRecord &r = chunk.records[i];
-    r.headerp = base + prev_end;
-    r.header_length = static_cast<readlen_t>(recs[i].seq_off - 1 - prev_end);
-    r.seqp = base + recs[i].seq_off;
-    r.qualp = base + recs[i].qual_off;
-    r.length = static_cast<readlen_t>(recs[i].len);
-    chunk.tot_reads_length += r.length;
-    chunk.headers_length += r.header_length;
-    prev_end = recs[i].qual_off + recs[i].len + 1;
-  }
-  return prev_end;
+  CompressionWorkspace::recordViews(chunk, recs);
+  return recs.empty() ? 0 : static_cast<std::size_t>(recs.back().qual_off) + recs.back().len + 1;
 }
 
 }  // namespace fqcomp28

@@ -132,6 +132,29 @@ int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, const fqgpu
                        uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,
                        size_t n_pos_cap, size_t *n_pos_len, unsigned flags);
 
+/* The same encode in two halves, so that the caller can work while the GPU does (the shim's
+ * encodeChunk codes the block's headers in between: src/workspace.cpp:25-31 does both in one
+ * per-record loop), and with the record table built on the GPU when the caller has none:
+ *   fqgpu_encode_begin    uploads the chunk (recs == NULL: finds its records on the device --
+ *                         FastqReader::parseRecords, src/fastq_io.cpp:67-125, which the reference runs
+ *                         under the reader mutex, :29-52 -- a trailing partial record is ignored),
+ *                         starts the encode and returns; *used_len = bytes up to the last complete record
+ *   fqgpu_encode_records  the record table of the block in flight (n_recs entries), without waiting
+ *                         for the encode
+ *   fqgpu_encode_wait     waits for the encode and reports the sizes of what it produced, so that the
+ *                         caller can size its buffers exactly (optional)
+ *   fqgpu_encode_end      waits, delivers exactly what fqgpu_encode_block delivers; `raw` may be NULL
+ *                         (no N -> A write-back).  Capacities below the stream sizes: FQGPU_E_OVERFLOW.
+ * One block in flight per handle (a block begun and never ended is dropped by the next begin); every
+ * other call on the handle waits for it. */
+int fqgpu_encode_begin(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs, size_t n_recs,
+                       unsigned flags, size_t *n_recs_out, size_t *n_bases_out, size_t *used_len);
+int fqgpu_encode_records(fqgpu_ctx *ctx, fqgpu_rec *recs_out, size_t cap);
+int fqgpu_encode_wait(fqgpu_ctx *ctx, size_t *seq_len, size_t *qual_len, size_t *n_pos_len);
+int fqgpu_encode_end(fqgpu_ctx *ctx, uint8_t *raw, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
+                     uint8_t *qual_out, size_t qual_cap, size_t *qual_len, uint16_t *readlens_out,
+                     uint16_t *n_count_out, uint16_t *n_pos_out, size_t n_pos_cap, size_t *n_pos_len);
+
 /* ---- block decode (replaces the second pass of
  * DecompressionWorkspace::decodeChunk, src/workspace.cpp:84-87:
  * SequenceDecoder::decodeRecord src/fse_sequence.cpp:114-143 and

@@ -2,11 +2,15 @@
 //   archive_tool copy <in.fqc> <out.fqc>      readBlock every block (index order) -> writeBlock -> writeIndex
 //   archive_tool dump <in.fqc>                per block: idx, sizes, and the misc streams after
 //                                             decompressMiscBuffers + header decoding, as hex / text
+//   archive_tool chunks <in.fastq> <bytes>    FastqReader with that reading size: "chunk <idx> <bytes>" per chunk
+//   archive_tool rejoin <in.fastq> <out.fastq> <bytes>   the same chunks through FastqWriter, LAST chunk first
+//                                             (reference test/fastq_io_test.cpp:15-53: reader -> writer identity)
 // tests/test_archive.py drives it against oracle/fqc_archive.py (an independent Python reading of
 // src/archive.h:10-17, src/archive.cpp:57-106).
 #include "../../fqcomp28_amd/csrc/archive.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 
 using namespace fqcomp28;
 
@@ -72,10 +76,28 @@ int main(int argc, char **argv) {
       }
       return 0;
     }
+    if ((argc == 4 && std::string(argv[1]) == "chunks") || (argc == 5 && std::string(argv[1]) == "rejoin")) {
+      const bool rejoin = argv[1][0] == 'r';
+      FastqReader reader(argv[2], static_cast<std::size_t>(std::atoll(argv[rejoin ? 4 : 3])));
+      std::vector<FastqChunk> chunks;
+      std::vector<uint64_t> at{0};
+      for (;;) {
+        chunks.emplace_back();
+        if (!reader.readNextChunk(chunks.back())) { chunks.pop_back(); break; }
+        if (!chunks.back().records.empty()) throw std::runtime_error("the reader hands out unparsed chunks");
+        std::printf("chunk %u %zu\n", chunks.back().idx, chunks.back().raw_data.size());
+        at.push_back(at.back() + chunks.back().raw_data.size());
+      }
+      if (rejoin) {
+        FastqWriter writer(argv[3], at);
+        for (std::size_t i = chunks.size(); i-- > 0;) writer.writeChunk(chunks[i]);
+      }
+      return 0;
+    }
   } catch (const std::exception &e) {
     std::printf("exception: %s\n", e.what());
     return 1;
   }
-  std::printf("usage: archive_tool copy <in> <out> | dump <in>\n");
+  std::printf("usage: archive_tool copy <in> <out> | dump <in> | chunks <fastq> <bytes> | rejoin <fastq> <out> <bytes>\n");
   return 2;
 }

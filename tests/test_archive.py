@@ -183,3 +183,71 @@ def test_truncated_archive_is_refused(F, tool, tmp_path, golden_dir):
     open(cut, "wb").write(data[: len(data) // 3])
     r = subprocess.run([tool, "dump", cut], capture_output=True, text=True)
     assert r.returncode == 1 and "exception" in r.stdout
+
+
+# ---------------------------------------------------------------- the FASTQ file ends of the farm
+def reference_chunks(raw, recs, reading_size):
+    """the chunks FastqReader::readNextChunk cuts (src/fastq_io.cpp:23-65): whole records of the next
+    reading_size bytes, the next chunk begins where this one ended"""
+    ends = (recs["qual_off"].astype(np.int64) + recs["len"] + 1)
+    out, begin = [], 0
+    while begin < ends[-1]:
+        k = int(np.searchsorted(ends, begin + reading_size, side="right")) - 1
+        if k < 0 or ends[k] <= begin:
+            raise ValueError("reading size smaller than one record")
+        out.append(int(ends[k]) - begin)
+        begin = int(ends[k])
+    return out
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_reader_cuts_the_reference_chunks_without_parsing(tool, tmp_path, golden_dir, name):
+    """The reader finds the end of a chunk by a backwards search for the last complete record (no
+    parse under its lock): same chunks as the reference's parse-everything reader for every reading
+    size, incl. files whose quality lines begin with '@' or '+' (these do), a file without a final
+    newline (its partial record is dropped) and reading sizes just above one record."""
+    path = os.path.join(golden_dir, name + ".fastq")
+    raw, recs = O.load_fastq(path)
+    biggest = int((np.diff(np.concatenate([[0], recs["qual_off"].astype(np.int64) + recs["len"] + 1]))).max())
+    sizes = sorted({biggest, biggest + 1, 1000, 1777, 4096, 65536, raw.size // 3, raw.size - 1, raw.size, raw.size + 10})
+    for size in sizes:
+        if size < biggest:
+            continue
+        r = subprocess.run([tool, "chunks", path, str(size)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+        got = [int(ln.split()[2]) for ln in r.stdout.splitlines() if ln.startswith("chunk ")]
+        assert got == reference_chunks(raw, recs, size), size
+    # reader -> writer identity with the chunks written last first (reference test/fastq_io_test.cpp:15-53)
+    back = str(tmp_path / "back.fastq")
+    assert subprocess.run([tool, "rejoin", path, back, "5000"], capture_output=True).returncode == 0
+    assert open(back, "rb").read() == raw.tobytes()
+    # a reading size below one record is an error, not a hang or an empty archive
+    r = subprocess.run([tool, "chunks", path, str(biggest // 2)], capture_output=True, text=True)
+    assert r.returncode == 1 and "smaller than one record" in r.stdout
+    # no newline at the end of the file: the unfinished record is dropped
+    cut = str(tmp_path / "cut.fastq")
+    open(cut, "wb").write(raw.tobytes()[:-1])
+    r = subprocess.run([tool, "chunks", cut, str(raw.size)], capture_output=True, text=True)
+    last_full = int(recs[-2]["qual_off"] + recs[-2]["len"] + 1)
+    assert r.returncode == 0 and [int(ln.split()[2]) for ln in r.stdout.splitlines() if ln.startswith("chunk ")] == [last_full]
+
+
+def test_quality_lines_that_look_like_headers_do_not_move_a_chunk_end(tool, tmp_path):
+    """'@' and '+' are quality characters: a record is recognised by its shape over four lines."""
+    recs = []
+    rng = np.random.default_rng(4)
+    for i in range(400):
+        L = int(rng.integers(3, 60))
+        seq = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, L)].tobytes()
+        q = bytearray(rng.integers(33, 75, L).astype(np.uint8).tobytes())
+        q[0] = ord("@") if i % 3 == 0 else ord("+") if i % 3 == 1 else q[0]
+        recs.append(b"@r%d +x\n" % i + seq + b"\n+\n" + bytes(q) + b"\n")
+    data = b"".join(recs)
+    path = str(tmp_path / "tricky.fastq")
+    open(path, "wb").write(data)
+    raw = np.frombuffer(data, dtype=np.uint8)
+    table = O.parse_fastq(raw)
+    for size in (200, 333, 1000, 4097):
+        r = subprocess.run([tool, "chunks", path, str(size)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+        assert [int(ln.split()[2]) for ln in r.stdout.splitlines() if ln.startswith("chunk ")] == reference_chunks(raw, table, size)

@@ -114,6 +114,79 @@ def test_cpp_farm_three_workers_every_block_matches_oracle(F, tool, tmp_path):
     assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
 
 
+def test_cpp_farm_two_logical_devices_and_four_workers(F, tool, tmp_path):
+    """`-d 0,0`: the farm's device list with G = 2 entries (both device 0 on a one-GPU box), so that
+    worker t -> devices[t mod G], one handle per worker on its device, and the process-wide cache of
+    page-locked blocks (allocated portable: a block pinned by one worker is reused by any other)
+    all run; the archive is the oracle's, block for block."""
+    raw, _ = F.synth_fastq(21 << 20, 4, seed=13)
+    src = tmp_path / "in.fastq"
+    raw.tofile(src)
+    arc = tmp_path / "out.fqc"
+    rep = run_tool(tool, "c", src, arc, "-t", 4, "-R", 2, "-S", 4, "-d", "0,0")
+    assert rep["devices"] == 2 and len(rep["blocks_per_worker"]) == 4 and sum(rep["blocks_per_worker"]) == rep["blocks"] >= 10
+    check_archive_against_oracle(F, str(arc), raw, 4 << 20)
+    back = tmp_path / "back.fastq"
+    rep2 = run_tool(tool, "d", arc, back, "-t", 4, "-d", "0,0")
+    assert rep2["devices"] == 2 and np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+
+
+def test_a_damaged_block_ends_the_farm_with_an_error_not_a_hang(F, tool, tmp_path):
+    """A worker that fails (corrupt FSE stream, malformed misc stream, truncated block) must bring the
+    whole command down with exit code 1: the other workers finish their block and stop.  (With an
+    ordered writer that waits for the failed worker's chunk this used to hang holding the GPU.)"""
+    raw, _ = F.synth_fastq(8 << 20, 2, seed=14)
+    src = tmp_path / "in.fastq"
+    raw.tofile(src)
+    arc = tmp_path / "ok.fqc"
+    run_tool(tool, "c", src, arc, "-t", 2, "-R", 1, "-S", 2)
+    data = bytearray(open(arc, "rb").read())
+    _, _, _, blocks, entries = A.read_archive(str(arc))
+    assert len(blocks) >= 6
+    off = sorted(e[0] for e in entries)[2]  # the third block in the file
+    for what, at in (("a bit inside the block's streams", off + 40 + len(blocks[0].seq) // 2), ("the size word of its first field", off + 12)):
+        bad = bytearray(data)
+        bad[at] ^= 0x10
+        path = tmp_path / "bad.fqc"
+        open(path, "wb").write(bad)
+        r = subprocess.run([tool, "d", str(path), str(tmp_path / "bad.fastq"), "-t", "3"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1, (what, r.stdout, r.stderr)
+        assert "fqc_tool:" in r.stderr
+
+
+def test_encode_from_an_unparsed_chunk_through_the_c_abi(F):
+    """fqgpu_encode_begin without a record table (the GPU finds the records), _records, _wait, _end:
+    the table is the host parser's, the streams are the oracle's, a partial record at the end of
+    the chunk is ignored and reported through used_len, N -> A lands in the caller's buffer."""
+    raw, _ = F.synth_fastq(5 << 20, 4, seed=15)
+    recs = F.parse_fastq(raw)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    for tail in (b"", b"@SYN.x partial\nACGT"):
+        chunk = np.concatenate([raw, np.frombuffer(tail, dtype=np.uint8)])
+        g = ctx.encode_raw(chunk, flags=1)
+        assert g["rc"] == 0 and g["used_len"] == raw.size and g["n_bases"] == int(recs["len"].sum())
+        assert np.array_equal(g["recs"], recs)
+        for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+            assert np.array_equal(g[k], e[k]), k
+        assert np.array_equal(g["raw_after"][: raw.size], e["raw_after"])
+    # with the caller's table: the same bytes; and a second begin without an end drops the first block
+    g = ctx.encode_raw(raw, flags=1, recs=recs)
+    assert g["rc"] == 0 and all(np.array_equal(g[k], e[k]) for k in ("seq", "qual", "n_pos"))
+    import ctypes
+    n = ctypes.c_size_t(0)
+    assert F.lib().fqgpu_encode_begin(ctx.h, raw.ctypes.data, raw.size, None, 0, 0, ctypes.byref(n), None, None) == 0
+    g = ctx.encode_raw(raw, flags=0)
+    assert g["rc"] == 0 and np.array_equal(g["seq"], e["seq"])
+    # malformed chunks are refused, and the handle works afterwards
+    bad = raw.copy()
+    bad[int(recs[3]["qual_off"]) - 2] = ord("x")  # the '+' line
+    assert ctx.encode_raw(bad)["rc"] == -4  # FQGPU_E_ARG
+    assert ctx.encode_raw(raw)["rc"] == 0
+    ctx.close()
+
+
 def test_cpp_farm_accumulated_n_tables_like_the_reference(F, tool, tmp_path):
     """--accumulate-n: a worker's CompressedBuffersDst is never cleared of n_count / n_pos
     (src/compressed_buffers.h:58-68); the archive still decodes (pops from the end)."""
