@@ -99,6 +99,7 @@ _PROTOS = {
     "fqgpu_dblock_fetch_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "fqgpu_dblock_load_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "fqgpu_ctx_set_lanes": (C.c_int, [C.c_void_p, C.c_uint]),
+    "fqgpu_ctx_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "fqgpu_ctx_set_seq_segment": (C.c_int, [C.c_void_p, C.c_uint]),
     "fqgpu_ctx_set_seq_group": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint]),
     "fqgpu_dblock_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

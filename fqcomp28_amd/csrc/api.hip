@@ -927,6 +927,26 @@ static int hp_block_acquire(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_
   return FQGPU_OK;
 }
 
+// Everything a block of this shape will need -- the staging block of the host-pointer calls and the
+// scratch of every encode lane -- allocated now: the first block of a worker otherwise pays half a
+// second of hipMalloc (2.3 GB of scratch per 256 MiB block and lane) inside its timed loop.
+extern "C" int fqgpu_ctx_reserve(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_t n_bases) {
+  if (!ctx || !raw_len || !n_recs || !n_bases || n_bases >= 0xFFF00000ull) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  if ((rc = fqgpu_sync(ctx))) return rc;
+  ctx->hp_pending = false;
+  fqgpu_dblock *b = nullptr;
+  if ((rc = hp_block_acquire(ctx, raw_len, n_recs, n_bases, fqgpu_bound_seq(n_bases), fqgpu_bound_qual(n_bases), n_bases / 64 + 1024, &b))) return rc;
+  if ((rc = ctx->hp_parse.cnt.reserve((raw_len / 4096 + 2) * 4)) || (rc = ctx->hp_parse.base.reserve((raw_len / 4096 + 3) * 4)) ||
+      (rc = ctx->hp_parse.nl_pos.reserve((n_recs * 4 + 8) * 4)))
+    return rc;
+  const unsigned first = ctx->next_lane;
+  for (unsigned l = 0; l < ctx->n_lanes && !rc; l++) rc = fq_encode_launch(ctx, b, 0, nullptr, nullptr, true);
+  ctx->next_lane = first;
+  return rc;
+}
+
 // Waits for everything the handle has queued before an error return: the caller's buffers (page-locked
 // vectors that go back to the pin cache, where another thread may pick them up) must not be read or
 // written by a copy that is still in flight.

@@ -115,7 +115,7 @@ int reserve_k1(EncScratch &sc, unsigned n_sym) {
 
 template <class M>
 int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b,
-                  const uint32_t *rec_start, uint8_t *out_dev, size_t cap, unsigned flags) {
+                  const uint32_t *rec_start, uint8_t *out_dev, size_t cap, unsigned flags, bool reserve_only = false) {
   EncScratch &sc = lane.enc[M::STREAM];
   const DevTables &tab = ctx->tab[M::STREAM];
   constexpr unsigned B = M::B;
@@ -192,6 +192,8 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     if ((rc = sc.tile_runs.reserve((size_t)n_tiles * ts_run_stride<M>() * sizeof(uint2)))) return rc;
     if ((rc = sc.tile_sync.reserve(sync_runcount_off + (size_t)n_tiles * 4))) return rc;
   }
+
+  if (reserve_only) return FQGPU_OK;  // (fqgpu_ctx_reserve: the scratch of a block of this shape exists now)
 
   uint16_t *ckey = sc.keys.as<uint16_t>();
   uint8_t *csym = reinterpret_cast<uint8_t *>(ckey + n_pad);
@@ -466,7 +468,7 @@ int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered) {
 // after the record-level kernels and joined before the N-position pass.  Blocks handed to
 // different lanes overlap on the device: the serial sequence chains of one block hide behind
 // the bandwidth-bound passes of the others.
-int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t wait, hipStream_t *done) {
+int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t wait, hipStream_t *done, bool reserve_only) {
   const unsigned R = (unsigned)b->n_recs;
   if (R == 0 || b->n_bases == 0) return FQGPU_E_ARG;
   EncLane *lp = fq_next_lane(ctx);
@@ -482,6 +484,13 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
   uint32_t *n_cnt32 = lane.n_cnt32.as<uint32_t>();
   uint32_t *lens32 = n_cnt32 + R;
   uint32_t *rec_start = lane.rec_start.as<uint32_t>();
+  if (reserve_only) {  // every allocation a block of this shape needs on this lane, nothing launched
+    const unsigned n_sym = (unsigned)b->n_bases;
+    if (fused_k1(ctx) && ((rc = reserve_k1<SeqModel>(lane.enc[0], n_sym)) || (rc = reserve_k1<QualModel>(lane.enc[1], n_sym)))) return rc;
+    if ((rc = lane.scan_tmp.reserve(((size_t)R / 1024 + 64) * 16))) return rc;
+    if ((rc = encode_stream<QualModel>(ctx, lane, lane.st_qual, b, rec_start, nullptr, 0, flags, true))) return rc;
+    return encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, nullptr, 0, flags, true);
+  }
 
   FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), st));
   const unsigned rec_blocks = (unsigned)min((size_t)(R + 3) / 4, (size_t)8192);  // k_npos: a wave per record

@@ -237,7 +237,7 @@ int fq_seq_pow_ensure(hipStream_t st, DevTables &t, unsigned n_models, unsigned 
 // done: receives the stream on which the block's last kernel was launched (copies of the results
 // ordered behind the encode go there), may be nullptr
 int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t wait = nullptr,
-                     hipStream_t *done = nullptr);
+                     hipStream_t *done = nullptr, bool reserve_only = false);
 int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered);
 int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks);
 int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);

@@ -82,19 +82,34 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
   if (set.devices.empty()) throw std::invalid_argument("compressFarm: no device");
   // every worker builds its workspace first (256 + 8192 tables on its GPU: the reference does the
   // same once per thread, src/workspace.h:62-64); the clock starts when all are ready
+  // ... and so are its buffers: device scratch for chunks of the reading size, page-locked chunk and
+  // stream buffers (half a second of hipMalloc / hipHostMalloc per worker that would otherwise sit
+  // inside its first block)
   std::vector<std::unique_ptr<CompressionWorkspace>> wksp(T);
-  detail::runWorkers(T, [&](unsigned t) { wksp[t] = std::make_unique<CompressionWorkspace>(&meta, set.devices[t % set.devices.size()]); });
+  std::vector<FastqChunk> chunks(T);
+  std::vector<CompressedBuffersDst> buffers(T);
+  detail::runWorkers(T, [&](unsigned t) {
+    wksp[t] = std::make_unique<CompressionWorkspace>(&meta, set.devices[t % set.devices.size()]);
+    wksp[t]->reserve(set.reading_chunk_size);
+    chunks[t].raw_data.reserve(set.reading_chunk_size);
+    buffers[t].seq.reserve(set.reading_chunk_size / 8 + (1u << 20));
+    buffers[t].qual.reserve(set.reading_chunk_size / 3 + (1u << 20));
+  });
   std::vector<InputStats> istats(T);
   std::vector<CompressedStats> cstats(T);
   FarmReport rep;
   rep.blocks_per_worker.assign(T, 0);
   const auto t0 = std::chrono::steady_clock::now();
   detail::runWorkers(T, [&](unsigned t) {
-    FastqChunk chunk;
-    CompressedBuffersDst cbs;
-    while (next_chunk(chunk)) {
+    FastqChunk &chunk = chunks[t];
+    CompressedBuffersDst &cbs = buffers[t];
+    for (;;) {
+      StageClock clk;
+      if (!next_chunk(chunk)) break;
+      clk.lap("read");
       if (!set.accumulate_n_buffers) { cbs.n_count.clear(); cbs.n_pos.clear(); }
       wksp[t]->encodeChunk(chunk, cbs);  // (an unparsed chunk has its records found on the GPU: the sums are known afterwards)
+      clk.lap("encodeChunk");
       istats[t].seq += chunk.tot_reads_length;
       istats[t].header += chunk.headers_length;
       istats[t].n_records += chunk.records.size();
@@ -105,6 +120,8 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
       cstats[t].n_blocks++;
       rep.blocks_per_worker[t]++;
       write_block(cbs);
+      clk.lap("write");
+      clk.done(chunk.idx);
     }
   }, stop);
   rep.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -21,7 +21,10 @@
 // fqgpu_strerror().  Header-only; link with libfqgpu.so.
 #pragma once
 
+#include <chrono>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <istream>
@@ -31,6 +34,7 @@
 #include <stdexcept>
 #include <string>
 #include <string_view>
+#include <utility>
 #include <vector>
 
 #include "../../include/fqgpu.h"
@@ -53,6 +57,12 @@ template <class T> struct HostAllocator {
     return static_cast<T *>(p);
   }
   void deallocate(T *p, std::size_t) { fqgpu_host_free(p); }
+  /** resize() of a chunk or stream buffer must not sweep hundreds of megabytes with zeros that the
+   *  file read / the copy from the GPU overwrites the next moment: elements are default-initialised */
+  template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+  template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) {
+    ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...);
+  }
   template <class U> bool operator==(const HostAllocator<U> &) const { return true; }
   template <class U> bool operator!=(const HostAllocator<U> &) const { return false; }
 };
@@ -161,6 +171,23 @@ struct CompressedBuffersSrc : CompressedBuffers {
   }
 };
 
+/** FQGPU_SHIM_TRACE=1: one line per block on stderr with the milliseconds of every stage of
+ *  encodeChunk (where a worker's time goes: DESIGN.md section 9) */
+struct StageClock {
+  bool on = std::getenv("FQGPU_SHIM_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  std::string line;
+  void lap(const char *name) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), " %s %.1f", name, std::chrono::duration<double, std::milli>(now - t).count());
+    line += buf;
+    t = now;
+  }
+  void done(unsigned idx) { if (on) std::fprintf(stderr, "block %u:%s\n", idx, line.c_str()); }
+};
+
 inline void fqgpuCheck(int rc, const char *what) {
   if (rc != FQGPU_OK) throw std::runtime_error(std::string(what) + ": " + fqgpu_strerror(rc));
 }
@@ -252,6 +279,8 @@ protected:
   explicit Workspace(const DatasetMeta *meta, int device)
       : meta_(meta), fmt_(meta->header_fmt), first_header_fields_(headers::fromHeader(meta->first_header, fmt_)) {
     fqgpuCheck(fqgpu_ctx_create(device, meta->ft_seq.get(), meta->ft_qual.get(), &ctx_), "Workspace");
+    // one block at a time per workspace (like the reference's): one encode lane, a quarter of the scratch
+    fqgpuCheck(fqgpu_ctx_set_lanes(ctx_, 1), "Workspace");
   }
   /** every chunk codes its first header against the dataset's first header (src/workspace.cpp:90-93) */
   void startNewChunk() { prev_header_fields_ = first_header_fields_; }
@@ -269,11 +298,18 @@ class CompressionWorkspace : public Workspace {
 public:
   explicit CompressionWorkspace(const DatasetMeta *meta, int device = 0) : Workspace(meta, device) {}
 
+  /** Device memory for chunks of up to chunk_bytes now instead of inside the first encodeChunk
+   *  (the farm calls it while it sets its workers up; the sizes assume records of 64 bytes or more) */
+  void reserve(std::size_t chunk_bytes) {
+    if (chunk_bytes) fqgpuCheck(fqgpu_ctx_reserve(ctx_, chunk_bytes, chunk_bytes / 64 + 1, chunk_bytes / 2 + 1), "reserve");
+  }
+
   /** Encodes reads into cbs, allocating memory in cbs as needed; mutates the chunk (N -> A).
    *  The chunk may come UNPARSED (records empty, as FastqReader hands it out): the GPU then finds the
    *  records, and chunk.records / the length sums are filled in from its table.  The GPU work is
    *  started first; the headers are coded on this thread while it runs. */
   void encodeChunk(FastqChunk &chunk, CompressedBuffersDst &cbs) {
+    StageClock clk;
     cbs.clear();
     cbs.chunk_idx = chunk.idx;
     auto *raw = reinterpret_cast<uint8_t *>(chunk.raw_data.data());
@@ -284,21 +320,25 @@ public:
     fqgpuCheck(fqgpu_encode_begin(ctx_, raw, chunk.raw_data.size(), parsed ? recs.data() : nullptr, recs.size(),
                                   FQGPU_F_WRITE_BACK_N, &R, &n_bases, &used),
                "encodeChunk");
+    clk.lap("begin");
     if (!parsed) {
       recs.resize(R);
       fqgpuCheck(fqgpu_encode_records(ctx_, recs.data(), R), "encodeChunk");
       if (used != chunk.raw_data.size()) throw std::invalid_argument("encodeChunk: the chunk does not end with a complete record");
       recordViews(chunk, recs);
     }
+    clk.lap("records");
     // ---- host work in the shadow of the GPU: the header fields
     cbs.header_fields.resize(fmt_.n_fields());
     cbs.original_size.header_fields.resize(fmt_.n_fields());
     for (auto &field : cbs.header_fields) field.clear();
     startNewChunk();
     for (const FastqRecord &r : chunk.records) headers::encodeHeader(r.header(), fmt_, prev_header_fields_, cbs.header_fields);
+    clk.lap("headers");
     // ---- the streams, at their exact sizes
     std::size_t seq_len = 0, qual_len = 0, n_pos_len = 0;
     fqgpuCheck(fqgpu_encode_wait(ctx_, &seq_len, &qual_len, &n_pos_len), "encodeChunk");
+    clk.lap("wait");
     cbs.seq.resize(seq_len);
     cbs.qual.resize(qual_len);
     cbs.readlens.resize(R * sizeof(readlen_t));
@@ -311,9 +351,12 @@ public:
                                 reinterpret_cast<uint16_t *>(cbs.readlens.data()), reinterpret_cast<uint16_t *>(cbs.n_count.data() + cnt_at),
                                 reinterpret_cast<uint16_t *>(cbs.n_pos.data() + pos_at), n_pos_len, &n_pos_len),
                "encodeChunk");
+    clk.lap("end");
     cbs.original_size.n_records = static_cast<uint32_t>(R);
     cbs.original_size.total = static_cast<uint32_t>(chunk.raw_data.size());
     compressMiscBuffers(cbs);
+    clk.lap("misc");
+    clk.done(chunk.idx);
   }
 
   /** The misc pass (the reference's compressMiscBuffers, src/workspace.cpp:176-213): readlens, n_count,

@@ -100,6 +100,10 @@ int fqgpu_ctx_set_seq_segment(fqgpu_ctx *ctx, unsigned symbols);
  * splits into min_groups such groups (0 = default 16, the waves of a workgroup).  Results never
  * depend on it. */
 int fqgpu_ctx_set_seq_group(fqgpu_ctx *ctx, unsigned max_segments, unsigned min_groups);
+/* Allocates now what blocks of up to this shape will need (staging block of the host-pointer calls,
+ * scratch of every encode lane): a worker calls it while it builds its workspace, so that its
+ * first block does not pay for the allocations.  Optional; everything grows on demand. */
+int fqgpu_ctx_reserve(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_t n_bases);
 /* Number of blocks the handle keeps in flight (encode lanes, 1..8, default 4): each
  * fqgpu_dblock_encode goes to the next lane (own HIP streams and scratch). */
 int fqgpu_ctx_set_lanes(fqgpu_ctx *ctx, unsigned lanes);
