@@ -384,9 +384,14 @@ extern "C" int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len,
   if (rc) return rc;
   if (!raw || !recs || !seq_ft_out || !qual_ft_out) return FQGPU_E_ARG;
   // the histogram pass itself accepts reads of any length (src/fse_sequence.cpp:145-169)
-  for (size_t i = 0; i < n_recs; i++)
+  size_t n_bases = 0;
+  unsigned min_len = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n_recs; i++) {
     if ((size_t)recs[i].seq_off + recs[i].len > raw_len || (size_t)recs[i].qual_off + recs[i].len > raw_len)
       return FQGPU_E_ARG;
+    n_bases += recs[i].len;
+    if (recs[i].len < min_len || recs[i].len > 65535u) min_len = recs[i].len > 65535u ? 0u : recs[i].len;
+  }
   const size_t ns = (size_t)FQGPU_SEQ_MODELS * FQGPU_SEQ_ALPHA, nq = (size_t)FQGPU_QUAL_MODELS * FQGPU_QUAL_ALPHA;
   uint8_t *raw_dev = fq_dev_alloc<uint8_t>(raw_len + 64);
   fqgpu_rec *recs_dev = fq_dev_alloc<fqgpu_rec>(n_recs + 1);
@@ -399,7 +404,7 @@ extern "C" int fqgpu_freq_tables(int device, const uint8_t *raw, size_t raw_len,
     if (hipMemcpy(raw_dev, raw, raw_len, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(recs_dev, recs, n_recs * sizeof(fqgpu_rec), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(cnt + ns + nq, 0, 4) != hipSuccess) { rc = FQGPU_E_HIP; break; }
-    if ((rc = fq_build_freq_tables(device, st, raw_dev, recs_dev, n_recs, cnt, cnt + ns))) break;
+    if ((rc = fq_build_freq_tables(device, st, raw_dev, recs_dev, n_recs, cnt, cnt + ns, n_bases, min_len))) break;
     if (hipMemcpy(&err, cnt + ns + nq, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = FQGPU_E_HIP; break; }
     if (err) { rc = FQGPU_E_ARG; break; }  // quality above Q63: the reference throws (src/fse_quality.cpp:88); a base byte outside ACGTN
     if (seq_counts_out && hipMemcpy(seq_counts_out, cnt, ns * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = FQGPU_E_HIP; break; }

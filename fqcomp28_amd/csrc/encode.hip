@@ -464,6 +464,114 @@ int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered) {
   return FQGPU_OK;
 }
 
+namespace {
+// (context, symbol) counts from the sorted symbols: one wave per 4096 symbols of one context's run,
+// a 64-bin histogram per wave in LDS (lanes that meet on the run's most frequent symbols are folded
+// into one add first), one global add per non-empty bin.
+__global__ void __launch_bounds__(256)
+k_hist_sorted_qual(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict__ arrays, unsigned S,
+                   uint32_t *__restrict__ counts) {
+  constexpr unsigned B = QualModel::B, A = QualModel::A;
+  __shared__ uint32_t s_bins[4][A];
+  const uint32_t *ctx_count = arrays, *ctx_start = arrays + B, *seg_base = ctx_start + B + 1;
+  const unsigned wave = threadIdx.x >> 6, lane = fq_lane(), seg = blockIdx.x * 4 + wave;
+  if (seg >= seg_base[B]) return;  // the grid is an upper bound
+  const unsigned c = seg_ctx_of<QualModel>(seg_base, seg), k = seg - seg_base[c];
+  const unsigned n = ctx_count[c], begin = k * S, end = min(n, begin + S);
+  const uint8_t *sym = sorted_sym + ctx_start[c];
+  uint32_t *bins = s_bins[wave];
+  bins[lane] = 0;
+  fq_lds_wave_sync();
+  for (unsigned p0 = begin; p0 < end; p0 += 1024) {
+    const unsigned p = p0 + 16 * lane;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p < end) v = *reinterpret_cast<const uint4 *>(sym + p);  // (runs are padded to 16 bytes)
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const unsigned s = (w[j >> 2] >> (8 * (j & 3))) & (A - 1);
+      bool on = p + j < end;
+      // the symbol of the first live lane: everybody who has it too is counted by that lane
+      const unsigned long long live = __ballot(on);
+      if (!live) break;  // (uniform)
+      const unsigned lead = (unsigned)__ffsll((long long)live) - 1u;
+      const unsigned s_lead = (unsigned)__shfl((int)s, (int)lead);
+      const unsigned long long same = __ballot(on && s == s_lead);
+      if (lane == lead) atomicAdd(&bins[s_lead], (unsigned)__popcll(same));
+      if (on && s != s_lead) atomicAdd(&bins[s], 1u);
+    }
+  }
+  fq_lds_wave_sync();
+  if (bins[lane]) atomicAdd(&counts[(size_t)c * A + lane], bins[lane]);
+}
+}  // namespace
+
+// FSE_Quality::calculateFreqTable (reference src/fse_quality.cpp:69-97) at the encoder's speed: the
+// (context, symbol) pairs of the sample are the ones the encoder's K1 computes (the context of a
+// position is the same from either end of the read), so K1 + K2 + K3 sort the symbols by context and
+// the counts are small local histograms of contiguous runs -- instead of 60 M atomics scattered
+// over a 2 MiB table in HBM (9 ms for a 128 MiB sample, 250 ms when one context holds most of it).
+// counts_dev: [8192][64], already filled with the reference's initial 1.  Reads of length >= 3 only.
+// Waits for st before it returns (its scratch is local).
+int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_rec *recs_dev, size_t n_recs, size_t n_bases,
+                          uint32_t *counts_dev, uint32_t *err_dev) {
+  constexpr unsigned B = QualModel::B, S = 4096;
+  const unsigned R = (unsigned)n_recs, n_sym = (unsigned)n_bases;
+  const unsigned n_tiles = (n_sym + TS_TILE - 1) / TS_TILE, n_groups = (n_tiles + GROUP_TILES - 1) / GROUP_TILES;
+  const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15, padded = (size_t)n_sym + (size_t)CTX_PAD * B + 64;
+  const unsigned max_segs = n_sym / S + B + 1;
+  EncLane lane;
+  EncScratch &sq = lane.enc[1], &ss = lane.enc[0];
+  DevBuf readlens, result;
+  int rc = FQGPU_OK;
+  do {
+    if ((rc = lane.rec_start.reserve((size_t)(R + 1) * 4)) || (rc = lane.n_cnt32.reserve((size_t)R * 8)) ||
+        (rc = readlens.reserve((size_t)R * 2)) || (rc = result.reserve(sizeof(BlockResult))) ||
+        (rc = reserve_k1<SeqModel>(ss, n_sym)) || (rc = reserve_k1<QualModel>(sq, n_sym)) ||
+        (rc = sq.slot_of.reserve(n_pad * 2)) || (rc = sq.sorted_sym.reserve(padded)) || (rc = sq.tile_base.reserve((size_t)n_tiles * B * 4)) ||
+        (rc = sq.group_sum.reserve((size_t)n_groups * B * 4)) || (rc = sq.ctx_arrays.reserve((size_t)(4 * B + 3) * 4)) ||
+        (rc = sq.tile_runs.reserve((size_t)n_tiles * ts_run_stride<QualModel>() * sizeof(uint2))) || (rc = sq.tile_sync.reserve((size_t)n_tiles * 4 + 64)))
+      break;
+    uint32_t *n_cnt32 = lane.n_cnt32.as<uint32_t>(), *lens32 = n_cnt32 + R, *rec_start = lane.rec_start.as<uint32_t>();
+    BlockResult *res = result.as<BlockResult>();
+    uint32_t *arrays = sq.ctx_arrays.as<uint32_t>();
+    uint16_t *kq = sq.keys.as<uint16_t>();
+    if (hipMemsetAsync(res, 0, sizeof(BlockResult), st) != hipSuccess) { rc = FQGPU_E_HIP; break; }
+    hipLaunchKernelGGL(k_readlens, dim3((unsigned)min((size_t)(R + 255) / 256, (size_t)2048)), dim3(256), 0, st, recs_dev, R,
+                       readlens.as<uint16_t>(), n_cnt32, lens32);
+    if ((rc = fq_scan_u32_to_u32(st, lens32, R, rec_start, lane.scan_tmp))) break;
+    hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, raw_dev, recs_dev, rec_start, R, n_sym, TS_TILE,
+                       ss.tile_hist.as<uint32_t>(), ss.keys.as<uint16_t>(), sq.tile_hist.as<uint32_t>(), kq,
+                       reinterpret_cast<uint8_t *>(kq + n_pad), n_cnt32, res);
+    hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st, sq.tile_hist.as<uint32_t>(), n_tiles, B, sq.group_sum.as<uint32_t>());
+    hipLaunchKernelGGL(k_group_prefix, dim3((B + 255) / 256), dim3(256), 0, st, sq.group_sum.as<uint32_t>(), n_groups, B, arrays);
+    hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, B, S, arrays, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st, sq.tile_hist.as<uint32_t>(), sq.group_sum.as<uint32_t>(),
+                       arrays + B, n_tiles, B, sq.tile_base.as<uint32_t>());
+    // (the rank only has to be a permutation here, not a stable one: no lane-ordered atomics are relied on)
+    hipLaunchKernelGGL(k_tile_partition<QualModel>, dim3(n_tiles), dim3(TS_THREADS), 0, st, kq, reinterpret_cast<uint8_t *>(kq + n_pad), n_sym,
+                       sq.tile_hist.as<uint32_t>(), sq.tile_base.as<uint32_t>(), sq.sorted_sym.as<uint8_t>(),
+                       reinterpret_cast<uint16_t *>(sq.slot_of.as<uint32_t>()), sq.tile_runs.as<uint2>(), sq.tile_sync.as<uint32_t>());
+    hipLaunchKernelGGL(k_hist_sorted_qual, dim3((max_segs + 3) / 4), dim3(256), 0, st, sq.sorted_sym.as<uint8_t>(), arrays, S, counts_dev);
+    BlockResult h;
+    if (hipMemcpyAsync(&h, res, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+        hipGetLastError() != hipSuccess) { rc = FQGPU_E_HIP; break; }
+    if (h.s[0].bad_symbol || h.s[1].bad_symbol) {  // a quality above Q63 / a byte that is no base: the caller reads the flag
+      uint32_t one = 1;
+      if (hipMemcpy(err_dev, &one, 4, hipMemcpyHostToDevice) != hipSuccess) rc = FQGPU_E_HIP;
+    }
+  } while (0);
+  (void)hipStreamSynchronize(st);
+  DevBuf *own[] = {&readlens, &result, &lane.rec_start, &lane.n_cnt32, &lane.n_off, &lane.scan_tmp};
+  for (DevBuf *b : own) b->release();
+  for (EncScratch *e : {&ss, &sq}) {
+    DevBuf *eb[] = {&e->slot_of, &e->keys, &e->sorted_sym, &e->out16, &e->tile_hist, &e->tile_base, &e->group_sum, &e->ctx_arrays,
+                    &e->tile_runs, &e->tile_sync, &e->scan_tmp};
+    for (DevBuf *b : eb) b->release();
+  }
+  return rc;
+}
+
 // One block = one encode lane: two HIP streams (sequence pipeline, quality pipeline) forked
 // after the record-level kernels and joined before the N-position pass.  Blocks handed to
 // different lanes overlap on the device: the serial sequence chains of one block hide behind

@@ -227,7 +227,7 @@ static inline size_t fq_index_snap_bytes(unsigned B) { return FQ_INDEX_SNAP_HEAD
 
 // ---------------------------------------------------------------- launches (encode.hip / decode.hip / tables.hip)
 int fq_build_freq_tables(int device, hipStream_t st, const uint8_t *raw_dev, const fqgpu_rec *recs_dev,
-                         size_t n_recs, uint32_t *seq_counts_dev, uint32_t *qual_counts_dev);
+                         size_t n_recs, uint32_t *seq_counts_dev, uint32_t *qual_counts_dev, size_t n_bases, unsigned min_len);
 int fq_normalize_counts(hipStream_t st, const uint32_t *counts_dev, int n_models, int alpha,
                         int16_t *norm_dev, uint32_t *logs_dev, uint32_t *max_log_dev, uint32_t *err_dev);
 int fq_build_tables(hipStream_t st, DevTables &t, int n_models, int alpha, uint32_t *err_dev);
@@ -241,6 +241,8 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
 int fq_probe_lds_atomic_order(hipStream_t st, bool *ordered);
 int fq_decode_launch(fqgpu_ctx *ctx, fqgpu_dblock *const *blocks, size_t n_blocks);
 int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);
+int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_rec *recs_dev, size_t n_recs, size_t n_bases,
+                          uint32_t *counts_dev, uint32_t *err_dev);
 int fq_parse_count(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, ParseScratch &ps, size_t *n_recs);
 int fq_parse_records(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, ParseScratch &ps, fqgpu_rec *recs_dev,
                      size_t n_recs, size_t *n_bases, size_t *n_n, size_t *used_len);

@@ -392,7 +392,7 @@ k_build_tables(const int16_t *__restrict__ norm, const uint32_t *__restrict__ lo
 }  // namespace
 
 int fq_build_freq_tables(int device, hipStream_t st, const uint8_t *raw_dev, const fqgpu_rec *recs_dev,
-                         size_t n_recs, uint32_t *seq_counts_dev, uint32_t *qual_counts_dev) {
+                         size_t n_recs, uint32_t *seq_counts_dev, uint32_t *qual_counts_dev, size_t n_bases, unsigned min_len) {
   (void)device;
   const size_t ns = (size_t)FQGPU_SEQ_MODELS * FQGPU_SEQ_ALPHA, nq = (size_t)FQGPU_QUAL_MODELS * FQGPU_QUAL_ALPHA;
   // counts start at 1 (src/fse_sequence.cpp:148-149, src/fse_quality.cpp:74-75)
@@ -402,8 +402,15 @@ int fq_build_freq_tables(int device, hipStream_t st, const uint8_t *raw_dev, con
     const unsigned blocks = (unsigned)min((n_recs + 3) / 4, (size_t)4096);
     uint32_t *err = qual_counts_dev + nq;  // caller provides one extra word
     hipLaunchKernelGGL(k_hist_seq, dim3(blocks), dim3(256), 0, st, raw_dev, recs_dev, (unsigned)n_recs, seq_counts_dev, err);
-    hipLaunchKernelGGL(k_hist_qual, dim3(blocks), dim3(256), 0, st, raw_dev, recs_dev, (unsigned)n_recs,
-                       qual_counts_dev, err);
+    // quality counts: through the encoder's sort when the sample is worth it (reads of three symbols or
+    // more: what the encoder's record walker is written for); the scattered-atomics kernel otherwise
+    if (min_len >= 3 && n_bases >= (1u << 20) && n_bases < 0xFFF00000ull) {
+      const int rc = fq_qual_counts_sorted(st, raw_dev, recs_dev, n_recs, n_bases, qual_counts_dev, err);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(k_hist_qual, dim3(blocks), dim3(256), 0, st, raw_dev, recs_dev, (unsigned)n_recs,
+                         qual_counts_dev, err);
+    }
   }
   FQ_HIP(hipGetLastError());
   return FQGPU_OK;

@@ -131,6 +131,26 @@ def test_tables_from_counts_normalisation_corner_cases(F):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", [2, 3, 4, 5])
+def test_dataset_analysis_through_the_encoders_sort_counts_what_the_reference_counts(F, mode):
+    """Samples of a million symbols and more take the quality histogram through the encoder's K1-K3
+    (symbols sorted by context, local histograms) instead of scattered atomics: the raw counts --
+    not only the normalised tables -- equal FSE_Quality::calculateFreqTable's (oracle), for the
+    BASELINE configs, binned qualities (few hot contexts) and one context only."""
+    raw, _ = F.synth_fastq(9 << 20, mode, seed=31)
+    recs = F.parse_fastq(raw)
+    assert int(recs["len"].sum()) > (1 << 20)
+    sc, qc, sft, qft = O.freq_tables(raw, recs)
+    gs, gq, gsc, gqc = F.freq_tables(raw, recs, want_counts=True)
+    assert np.array_equal(gsc, sc) and np.array_equal(gqc, qc)
+    assert gs.tobytes() == sft.tobytes() and gq.tobytes() == qft.tobytes()
+    # a quality above Q63 is refused on this path too (src/fse_quality.cpp:88 throws)
+    bad = raw.copy()
+    bad[int(recs[len(recs) // 2]["qual_off"]) + 5] = 33 + 64
+    with pytest.raises(F.FqgpuError):
+        F.freq_tables(bad, recs)
+
+
 # ---------------------------------------------------------------- how the chains are cut never shows in the output
 @pytest.mark.parametrize("seg,seq_generic,lanes", [(2, True, 1), (16, True, 3), (64, False, 2), (100000, True, 1),
                                                    (1024, False, 4)])
