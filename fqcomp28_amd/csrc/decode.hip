@@ -14,6 +14,7 @@
 // more chains than the chip has places (fq_decode_launch).
 #include "fqgpu_internal.h"
 
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -97,15 +98,21 @@ __device__ __forceinline__ unsigned peek_bits(g_cu32 *w, long long lo, unsigned 
 // time, once per ~16 K bits); position = 32 * wdw + avail, 0 <= avail < 32.
 constexpr unsigned FQ_BITBUF_DW = 512;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// The position is (d_lo, rel): the scalar register pair W holds stream dwords d_lo (low half) and
+// d_lo + 1, the unread bits end at bit `rel` of W, 32 <= rel < 64 before every read.  A read of nb <= 12
+// bits is three scalar instructions (subtract, 64-bit shift, mask); when rel drops below 32 the
+// window slides down one dword, which was asked for from the LDS buffer at the previous slide.  (Until
+// round 3 every read fetched its two dwords from LDS into vector registers: four more instructions and
+// one more LDS operation in front of the entry read of the chain, per symbol.)
 struct LdsBits {
   g_cu32 *w;
   lds_u32 *buf;         // LDS: stream dwords [buf_lo, buf_lo + FQ_BITBUF_DW)
-  unsigned buf_bits;    // 8 * LDS byte address of buf (a multiple of 32)
   unsigned n_dw;        // dwords of the stream (reads beyond are zeros)
   int buf_lo;
-  // the read position as a BIT address in LDS: buf_bits + 32 * (stream dword - buf_lo) + bit; one
-  // subtraction per read, the dword's LDS address and the shift count are both cut out of it
-  unsigned p;
+  unsigned long long W; // (wave-uniform: scalar registers)
+  int d_lo;             // stream dword in the low half of W; dwords below 0 read as zero (corrupt stream)
+  unsigned rel;
+  unsigned vnext;       // dword d_lo - 1, asked for (per lane: the same value in every lane)
   unsigned underflow;   // a read went below bit 0 (corrupt stream)
   __device__ __forceinline__ void fill(int top_dw) {  // all lanes; afterwards the buffer ends with dword top_dw
     buf_lo = top_dw >= (int)FQ_BITBUF_DW - 1 ? top_dw - ((int)FQ_BITBUF_DW - 1) : 0;
@@ -113,36 +120,44 @@ struct LdsBits {
     for (unsigned k = threadIdx.x; k < FQ_BITBUF_DW; k += 64) buf[k] = (unsigned)buf_lo + k < n_dw ? w[(unsigned)buf_lo + k] : 0u;
     fq_lds_wave_sync();
   }
-  __device__ __forceinline__ void place(int wdw, int avail) {  // position = bit `avail` of stream dword wdw
+  // dword i of the stream out of the buffer (i < 0: zero); the buffer is moved when i lies below it
+  __device__ __forceinline__ unsigned dword(int i) {
+    if (i < 0) return 0u;
+    if (i < buf_lo) fill(i + 1 < (int)FQ_BITBUF_DW ? (int)FQ_BITBUF_DW - 1 : i + 1);  // (as far up as keeps dword i inside and dword 0 at the bottom when possible)
+    return buf[i - buf_lo];
+  }
+  __device__ __forceinline__ void place(long long pos0) {  // position = absolute bit pos0 >= 0
+    const int wdw = (int)(pos0 >> 5);
     fill(wdw + 1);
-    p = buf_bits + 32u * (unsigned)(wdw - buf_lo) + (unsigned)avail;
+    const unsigned hi = fq_uniform(dword(wdw)), lo = fq_uniform(dword(wdw - 1));
+    W = ((unsigned long long)hi << 32) | lo;
+    d_lo = wdw - 1;
+    rel = 32u + (unsigned)(pos0 & 31);
+    vnext = dword(d_lo - 1);
   }
   __device__ __forceinline__ void init(g_cu32 *words, long long pos0, uint32_t *lds, unsigned stream_dwords) {
     w = words; buf = (lds_u32 *)lds; n_dw = stream_dwords; underflow = 0;
-    buf_bits = __builtin_amdgcn_readfirstlane((unsigned)(size_t)buf) * 8u;
-    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pos0), phi = __builtin_amdgcn_readfirstlane((unsigned)(pos0 >> 32));
-    const long long pu = ((long long)phi << 32) | plo;
-    place((int)(pu >> 5), (int)(pu & 31));
+    const unsigned plo = fq_uniform((unsigned)pos0), phi = fq_uniform((unsigned)(pos0 >> 32));
+    place(((long long)phi << 32) | plo);
   }
-  __device__ __forceinline__ long long pos() const { return underflow ? -1ll : (long long)buf_lo * 32 + (long long)(p - buf_bits); }
-  // the rare part of advance(): the buffer has run out, or the stream has (corrupt: the caller checks
-  // pos(); what is read from then on is arbitrary but stays inside the tables)
-  __device__ __forceinline__ void turn() {
-    const int rel = (int)(p - buf_bits);  // < 0: in the dword below the buffer
-    int wdw = buf_lo + (rel >> 5), avail = rel & 31;
-    if (wdw < 0) { underflow = 1; wdw = 0; avail = 0; }
-    place(wdw, avail);
+  __device__ __forceinline__ long long pos() const { return underflow ? -1ll : (long long)d_lo * 32 + (long long)rel; }
+  // the window moves down one dword (rel < 32): every 32 bits, i.e. every 5 .. 30 symbols
+  __device__ __forceinline__ void slide() {
+    W = (W << 32) | fq_uniform(vnext);
+    d_lo--;
+    rel += 32u;
+    if (d_lo < -1) underflow = 1;  // (what is read from then on is zeros: arbitrary but inside the tables; the caller checks pos())
+    vnext = dword(d_lo - 1);
   }
-  // A read in two parts, so that the walk can put the LDS access where it wants it: advance(nb) moves
-  // the position below the nb bits and returns the two stream dwords they lie in, bits() cuts them out.
-  __device__ __forceinline__ uint2 advance(unsigned nb) {  // nb <= 12; uniform
-    p -= nb;
-    if (__builtin_expect(p < buf_bits, 0)) turn();
-    const lds_u32 *q = reinterpret_cast<const lds_u32 *>((p >> 3) & ~3u);
-    return make_uint2(q[0], q[1]);
-  }
-  __device__ __forceinline__ unsigned bits(uint2 win, unsigned nb) const {
-    return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(win.y, win.x, p), 0u, nb);  // (the shift is p mod 32)
+  // the next nb bits (nb <= 12; uniform)
+  // (the window is looked after every SECOND read: 32 <= rel before two reads of at most 12 bits each leaves
+  // rel >= 8, and one slide brings it back above 32 -- a compare and a branch less every other symbol)
+  __device__ __forceinline__ unsigned read(unsigned nb, bool look_after) {
+    rel -= nb;
+    unsigned v = (unsigned)(W >> rel) & ((1u << nb) - 1u);
+    asm volatile("" : "+s"(v));  // cut out before the slide's branch: sunk behind it, both versions of W stay live (two copies per symbol)
+    if (look_after && __builtin_expect(rel < 32u, 0)) slide();
+    return v;
   }
 };
 
@@ -150,19 +165,47 @@ struct LdsBits {
 // arrive as symbol * 8 (the entry's symbol field as it is), slot() = 8 * context.
 // sequence: the context itself; quality: the last three symbols
 template <class M> struct CtxHist;
+// next(s8) = slot of the context behind symbol s8, with as little as possible between the symbol and
+// the slot (that is the chain): the part of the next context that does not depend on the new symbol
+// (`pre`) is worked out one symbol earlier, in push().
 template <> struct CtxHist<SeqModel> {
-  unsigned c8;
-  __device__ __forceinline__ void start() { c8 = 0xD7u * 8u; }  // FSE_Sequence::INITIAL_CONTEXT
+  unsigned c8, pre;
+  __device__ __forceinline__ void start() { c8 = 0xD7u * 8u; pre = (c8 >> 2) & ~7u; }  // FSE_Sequence::INITIAL_CONTEXT
   __device__ __forceinline__ unsigned slot() const { return c8; }
-  __device__ __forceinline__ void push(unsigned s8) { c8 = ((c8 >> 2) & ~7u) + (s8 << 6); }  // addSymUpper
+  __device__ __forceinline__ unsigned next(unsigned s8) const { return pre + (s8 << 6); }  // addSymUpper
+  __device__ __forceinline__ void push(unsigned s8) {
+    c8 = pre + (s8 << 6);
+    pre = (c8 >> 2) & ~7u;
+    asm volatile("" : "+s"(pre));  // worked out HERE, in the shadow of the entry read (volatile asm keeps its place among the walk's other asm), not sunk into the next step's chain
+  }
+  // one base of the history in front of the first position of a walk (no scalar-register pin: see uniform())
+  __device__ __forceinline__ void seed(unsigned s8) { c8 = pre + (s8 << 6); pre = (c8 >> 2) & ~7u; }
+  // the walk keeps the history in scalar registers: what was seeded from memory is made provably uniform
+  __device__ __forceinline__ void uniform() { c8 = fq_uniform(c8); pre = fq_uniform(pre); }
 };
 template <> struct CtxHist<QualModel> {
-  unsigned q, q1, q2;  // 8 * symbols k-1, k-2, k-3
-  __device__ __forceinline__ void start() { q = q1 = q2 = 0; }
-  __device__ __forceinline__ unsigned slot() const {  // calcContext (fq_qual_ctx), times 8
-    return ((q1 > q2 ? q1 : q2) << 6) | q | ((unsigned)(q1 == q2) << 15);
+  unsigned q, q1, pre;  // 8 * symbols k-1, k-2; pre = what symbols k-1 and k-2 give the context of symbol k + 1
+  __device__ __forceinline__ void start() { q = q1 = 0; pre = cur_slot = 1u << 15; }
+  __device__ __forceinline__ unsigned slot() const { return cur_slot; }
+  unsigned cur_slot;
+  // calcContext (fq_qual_ctx), times 8: (max(q1, q2) << 6) | q | (q1 == q2) << 15 with q = the new symbol
+  __device__ __forceinline__ unsigned next(unsigned s8) const { return pre | s8; }
+  __device__ __forceinline__ void push(unsigned s8) {
+    cur_slot = pre | s8;
+    q1 = q; q = s8;
+    pre = ((q > q1 ? q : q1) << 6) | ((unsigned)(q == q1) << 15);
+    asm volatile("" : "+s"(pre));  // (see above)
   }
-  __device__ __forceinline__ void push(unsigned s8) { q2 = q1; q1 = q; q = s8; }
+  // history in front of the first position of a walk: symbols k-1, k-2, k-3 (8 * symbol each)
+  __device__ __forceinline__ void set(unsigned a, unsigned b, unsigned c) {
+    q = a; q1 = b;
+    cur_slot = ((b > c ? b : c) << 6) | a | ((unsigned)(b == c) << 15);
+    pre = ((a > b ? a : b) << 6) | ((unsigned)(a == b) << 15);
+  }
+  __device__ __forceinline__ void uniform() {
+    q = fq_uniform(q); q1 = fq_uniform(q1);
+    pre = fq_uniform(pre); cur_slot = fq_uniform(cur_slot);
+  }
 };
 
 // What a stream's walk carries from read to read: the per-context entries (LDS) and the table.
@@ -182,7 +225,7 @@ struct WalkT {
   using Slots = typename std::conditional<COMPACT, uint32_t, CtxEntry>::type;
   __device__ __forceinline__ void init(Slots *lds, const uint32_t *tables, const uint32_t *table_offsets) {
     ce = (lds_char *)(__attribute__((address_space(3))) Slots *)lds;
-    ce_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ce);
+    ce_lds = fq_uniform((unsigned)(size_t)ce);
     dt = tables;
     dt_off = table_offsets;
   }
@@ -200,7 +243,7 @@ struct WalkT {
   // refills own), valid behind settle()
   __device__ __forceinline__ uint32_t ask_table(unsigned slot) const {
     uint32_t t = 0;
-    if (COMPACT) asm volatile("s_load_dword %0, %1, %2" : "=s"(t) : "s"(dt_off), "s"(__builtin_amdgcn_readfirstlane(slot >> 1)) : "memory");
+    if (COMPACT) asm volatile("s_load_dword %0, %1, %2" : "=s"(t) : "s"(dt_off), "s"(fq_uniform(slot >> 1)) : "memory");
     return t;
   }
   static __device__ __forceinline__ void settle(uint32_t &t) {
@@ -215,7 +258,7 @@ struct WalkT {
   // in between may return out of order: lgkmcnt(0).)
   // M0 is not restored: nothing else in these kernels uses it (no other LDS-DMA, no movrel).
   __device__ __forceinline__ void refill(unsigned slot, unsigned off) const {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(ce_lds + lds_of(slot));
+    const unsigned dst = fq_uniform(ce_lds + lds_of(slot));
     if (COMPACT)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 1\n\t"
                    "global_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
@@ -225,12 +268,24 @@ struct WalkT {
                    "global_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1"
                    : : "v"(off), "s"(dt), "s"(dst) : "memory");
   }
+  // the table dword at byte offset `off`, now (scalar load; waits for it)
+  __device__ __forceinline__ uint32_t fetch(unsigned off) const {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(dt), "s"(off) : "memory");
+    return v;
+  }
   // entry of the context from what load(slot) returned; a pending entry is waited for
   __device__ __forceinline__ uint32_t take(unsigned slot, uint2 e) const {
-    uint32_t entry = __builtin_amdgcn_readfirstlane(e.x);
+    unsigned unused = 0;
+    return take(slot, e, ~0u, unused);
+  }
+  // ... `left` = the slot the walk has just left: coming straight back to it is counted in `runs`
+  __device__ __forceinline__ uint32_t take(unsigned slot, uint2 e, unsigned left, unsigned &runs) const {
+    uint32_t entry = fq_uniform(e.x);
     if (__builtin_expect(entry == FQ_ENTRY_PENDING, 0)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      entry = __builtin_amdgcn_readfirstlane(*entry_at(slot));
+      entry = fq_uniform(*entry_at(slot));
+      runs += slot == left;
     }
     return entry;
   }
@@ -248,6 +303,8 @@ __device__ __forceinline__ unsigned fq_sym_bytes(unsigned acc) {
 // and kept in scalar registers.  Lane k keeps output bytes 4k .. 4k + 3 of the current 256.
 template <class M, bool COMPACT>
 __device__ __forceinline__ void walk_positions(WalkT<COMPACT> &wk, LdsBits &br, g_u8 *out, unsigned i0, unsigned i1, CtxHist<M> h) {
+  i0 = fq_uniform(i0);  // (uniform by construction; said so, so that the trip counts and with them the
+  i1 = fq_uniform(i1);  //  walk's whole state stay in scalar registers)
   if (i0 >= i1) return;
   const unsigned lane = threadIdx.x;
   unsigned slot = h.slot();
@@ -256,41 +313,89 @@ __device__ __forceinline__ void walk_positions(WalkT<COMPACT> &wk, LdsBits &br, 
   uint32_t cur = wk.take(slot, e);
   wk.settle(toff);
   unsigned keep = 0, acc = 0;
-  // one symbol; j = its byte in acc.  Order: the stream dwords of this symbol's bits are asked for
-  // first (their address needs nbBits only), then the next context's entry (the chain); the refill's
-  // arithmetic runs while that entry is on its way.  Entry fields: FQ_DENTRY (fqgpu_internal.h).
-  auto step = [&](unsigned j) {
-    const unsigned nb = (cur >> 9) & 15u;
-    const uint2 win = br.advance(nb);
+  // One symbol; j = its byte in acc.  ORDER IS THE POINT: the chain of a stream is entry -> symbol ->
+  // next context -> LDS read of that context's entry, and a lone wave issues one instruction every four
+  // cycles or so -- whatever stands between `cur` and the issue of that read delays the next symbol.
+  // So the mark of the slot being left (its address sits in a register since the last step) and the
+  // read of the next entry go first, pinned by a scheduling barrier; everything else -- this symbol's
+  // bits (scalar), the refill's address, the output byte, the half of the NEXT context that does not
+  // depend on the next symbol -- runs while that read is on its way.  Entry fields: FQ_DENTRY.
+  //
+  // RUN = the form of the step that also knows what to do when a context FOLLOWS ITSELF (a run of one
+  // quality value, a homopolymer).  Through the slot that costs a wait for this very symbol's refill
+  // -- an L2 round trip plus an LDS one per symbol: 160 ns on binned or constant data --, so there
+  // the next entry, dt[table + new state], is fetched directly by a scalar load (the tables are
+  // read-only) and the slot is left alone, stale, until the context is left: the step that leaves it
+  // marks and refills the slot from `cur` as always.  The test and its branch cost every symbol a few
+  // cycles and the registers their copies, so the plain form runs until its slow path has met such
+  // a context (`runs`), and the RUN form as long as it keeps meeting one: the switch is made between
+  // groups of four symbols.
+  unsigned runs = 0;   // self-following contexts met in the current group of four (counted twice in the RUN form)
+  unsigned tbl_s = 0;  // RUN form: table of the current context (scalar)
+  bool tail = false;  // the last one to three symbols of a walk: every read looks after the window
+  auto step = [&](unsigned j, auto run_form) {
+    constexpr bool RUN = decltype(run_form)::value;
     const unsigned s8 = cur & (unsigned)((M::A - 1) << 3);
-    h.push(s8);
-    const unsigned nslot = h.slot();
+    const unsigned nslot = h.next(s8);
+    if (RUN && nslot == slot) {
+      const unsigned nb = (cur >> 9) & 15u;
+      const unsigned bits = br.read(nb, (j & 1u) != 0 || tail);
+      h.push(s8);
+      acc |= (s8 >> 3) << (8u * j);
+      cur = wk.fetch((cur >> 16) + (bits << 2) + tbl_s);
+      runs += 2;
+      return;
+    }
     wk.mark(slot);
     const uint2 ne = wk.load(nslot);
     uint32_t ntoff = wk.ask_table(nslot);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned nb = (cur >> 9) & 15u;
+    const unsigned bits = br.read(nb, (j & 1u) != 0 || tail);
+    h.push(s8);
     // (e.y, the table's byte offset, stays in its vector register; COMPACT: the state-0 entry is word dt_off + 1)
-    const unsigned off = COMPACT ? (cur >> 16) + ((br.bits(win, nb) + (toff + 1u)) << 2) : (cur >> 16) + ((br.bits(win, nb) << 2) + e.y);
+    const unsigned off = COMPACT ? (cur >> 16) + ((bits + (toff + 1u)) << 2) : (bits << 2) + ((cur >> 16) + e.y);
     acc |= (s8 >> 3) << (8u * j);
     wk.refill(slot, off);
+    const unsigned left = slot;
     slot = nslot;
     e = ne;
-    cur = wk.take(slot, e);  // (one too many at the end of a read: the next read starts from another context)
+    cur = wk.take(slot, e, left, runs);  // (one too many at the end of a read: the next read starts from another context)
     wk.settle(ntoff);
     toff = ntoff;
+    if (RUN) tbl_s = COMPACT ? (toff + 1u) << 2 : fq_uniform(e.y);  // byte offset of the context's table, for the direct fetch
   };
   g_u8 *o = out + i0;
   const unsigned n = i1 - i0;
   unsigned g = 0;  // symbols done
-  for (; g + 4 <= n; g += 4) {
-    acc = 0;
-    step(0); step(1); step(2); step(3);
-    const unsigned slot = (g >> 2) & 63u;
-    keep = lane == slot ? fq_sym_bytes<M>(acc) : keep;
-    if (slot == 63u) *reinterpret_cast<FQ_GLOBAL uint32_t *>(o + (g - 252u) + 4u * lane) = keep;  // (reads start anywhere: unaligned dwords)
+  auto group_done = [&] {
+    const unsigned kslot = (g >> 2) & 63u;
+    keep = lane == kslot ? fq_sym_bytes<M>(acc) : keep;
+    if (kslot == 63u) *reinterpret_cast<FQ_GLOBAL uint32_t *>(o + (g - 252u) + 4u * lane) = keep;  // (reads start anywhere: unaligned dwords)
+  };
+  while (g + 4 <= n) {
+    for (runs = 0; g + 4 <= n && runs < 2; g += 4) {  // the plain form, until a group meets two such contexts
+      acc = 0;
+      runs = 0;
+      step(0, std::false_type()); step(1, std::false_type()); step(2, std::false_type()); step(3, std::false_type());
+      group_done();
+    }
+    if (g + 4 <= n) tbl_s = COMPACT ? (toff + 1u) << 2 : fq_uniform(e.y);
+    for (; g + 4 <= n && runs >= 2; g += 4) {  // the form for runs, as long as every group has one
+      acc = 0;
+      runs = 0;
+      step(0, std::true_type()); step(1, std::true_type()); step(2, std::true_type()); step(3, std::true_type());
+      group_done();
+    }
   }
   const unsigned r = n - g;  // < 4 symbols left
   acc = 0;
-  for (unsigned j = 0; j < r; j++) step(j);
+  tbl_s = COMPACT ? (toff + 1u) << 2 : fq_uniform(e.y);
+  tail = true;
+  for (unsigned j = 0; j < r; j++) step(j, std::true_type());
+  // a read that ends inside a run leaves the run's context with a stale slot (the self-following path above
+  // does not touch it): the entry the context is in goes there now (anywhere else this writes what is there)
+  *wk.entry_at(slot) = cur;
   const unsigned full = (g >> 2) & 63u;  // whole dwords not stored yet
   const unsigned base = g - 4u * full;
   if (lane < full) *reinterpret_cast<FQ_GLOBAL uint32_t *>(o + base + 4u * lane) = keep;
@@ -393,7 +498,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
       set_slot(ce, c, table, tab.dt[table + ((unsigned)st[c] & ((1u << tab.logs[c]) - 1u))]);  // a damaged index must not leave the table
     }
     pos = (long long)*reinterpret_cast<const unsigned long long *>(snap);
-    prev = reinterpret_cast<const uint32_t *>(snap)[2];
+    prev = fq_uniform(reinterpret_cast<const uint32_t *>(snap)[2]);  // (uniform: the walk's history lives in scalar registers)
     if (pos > (long long)len * 8) { if (lane == 0) res->corrupt = 1; return; }
   }
   __syncthreads();
@@ -420,15 +525,15 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
       if constexpr (M::STREAM == 0) {
         for (int b = 3; b >= 0; b--) {
           const unsigned ch = (prev >> (8 * b)) & 0xFFu;
-          if (ch != 0xFFu) h.push(fq_base_code(ch) * 8u);
+          if (ch != 0xFFu) h.seed(fq_base_code(ch) * 8u);
         }
       } else {
         const unsigned a = prev & 0xFFu, b = (prev >> 8) & 0xFFu, c = (prev >> 16) & 0xFFu;
-        h.q = a != 0xFFu ? ((a - 33u) & 63u) * 8u : 0u;
-        h.q1 = b != 0xFFu ? ((b - 33u) & 63u) * 8u : 0u;
-        h.q2 = c != 0xFFu ? ((c - 33u) & 63u) * 8u : 0u;
+        h.set(a != 0xFFu ? ((a - 33u) & 63u) * 8u : 0u, b != 0xFFu ? ((b - 33u) & 63u) * 8u : 0u,
+              c != 0xFFu ? ((c - 33u) & 63u) * 8u : 0u);
       }
     }
+    h.uniform();
     walk_positions<M, COMPACT>(wk, br, raw + (M::STREAM == 0 ? rec.seq_off : rec.qual_off), i0, i1, h);
     first = false;
     if (br.underflow || rs <= e_lo || r == 0) break;

@@ -262,6 +262,13 @@ void fq_timer_span_end(fqgpu_ctx *ctx, hipStream_t st);
 
 __device__ __forceinline__ unsigned fq_lane() { return threadIdx.x & 63u; }
 
+// v_readfirstlane as an UNSIGNED value.  The builtin's type is int: `u64 | __builtin_amdgcn_readfirstlane(x)`
+// sign-extends, i.e. ORs thirty-two ones into the upper half whenever bit 31 of x is set.  That -- not a
+// hardware hazard -- was the "wrong bits" of round 2's scalar bit window in the decode walk (the ISA showed
+// s_ashr_i32 hi, lo, 31 in front of the s_or_b64 that slides the window; tests/test_build_invariants.py
+// keeps both out of decode.hip).  decode.hip uses this wrapper only.
+__device__ __forceinline__ unsigned fq_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
 // LDS ordering inside ONE wave (single-wave workgroups): the LDS executes a wave's
 // instructions in order, so all that is needed is that earlier LDS operations have completed
 // and that the compiler does not move LDS accesses across this point.  __syncthreads() would
