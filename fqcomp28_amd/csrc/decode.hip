@@ -256,7 +256,10 @@ struct WalkT {
   // behind the mark (the compiler cannot swap the two: they may alias), so at most that load, or
   // one behind it, is still on its way -- the mark has landed.  (COMPACT: the scalar load asked for
   // in between may return out of order: lgkmcnt(0).)
-  // M0 is not restored: nothing else in these kernels uses it (no other LDS-DMA, no movrel).
+  // M0 is not restored and cannot be declared clobbered (hipcc: "reserved register"): nothing else in these
+  // kernels uses it -- no other LDS-DMA, no movrel -- which tests/test_build_invariants.py checks on the ISA.
+  // EXEC is set back to all ones, not restored: the walk runs with the full wave (decode_stream / decode_chunk
+  // check that on entry and refuse to run otherwise).
   __device__ __forceinline__ void refill(unsigned slot, unsigned off) const {
     const unsigned dst = fq_uniform(ce_lds + lds_of(slot));
     if (COMPACT)
@@ -417,6 +420,7 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, typename Walk
   g_crec *recs = (g_crec *)j.recs;
   g_u8 *raw = (g_u8 *)j.raw;
 
+  if (__ballot(1) != ~0ull) { res->corrupt = 1; return; }  // (the refill's assembly sets EXEC to all ones: a partial wave must not get there)
   // BIT_initDStream: the highest set bit of the last byte is the end mark
   const unsigned last = len ? src[len - 1] : 0u;
   if (last == 0) { if (lane == 0) res->corrupt = 1; return; }
@@ -474,6 +478,7 @@ __device__ void decode_chunk(const DecJob &j, unsigned chunk, const TabView &tab
   const unsigned n_sym = (unsigned)hdr.n_sym, stride = hdr.stride;
   const unsigned e_lo = chunk * stride, e_hi = min(e_lo + stride, n_sym);
   const bool from_end = chunk == hdr.n_snap;  // the last stride starts at the stream's end mark
+  if (__ballot(1) != ~0ull) { res->corrupt = 1; return; }  // (see decode_stream)
 
   long long pos;
   unsigned prev = 0xFFFFFFFFu;

@@ -29,6 +29,33 @@ def test_decode_walk_owns_m0_and_has_no_scratch(tmp_path):
     assert "scratch_" not in text
 
 
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_decode_walk_never_sign_extends_a_stream_word(tmp_path):
+    """Round 2's "wrong bits with the bit window in scalar registers" was no hardware hazard: the
+    builtin behind v_readfirstlane returns int, so `window << 32 | readfirstlane(word)` sign-extended --
+    the ISA had `s_ashr_i32 hi, lo, 31` in front of the `s_or_b64` that slides the window, i.e. 32 ones
+    in the upper half whenever bit 31 of the incoming stream word was set.  decode.hip therefore goes
+    through fq_uniform() (unsigned in, unsigned out) only, and its ISA holds no arithmetic shift by 31
+    that feeds a 64-bit OR."""
+    src = open(os.path.join(ROOT, "fqcomp28_amd", "csrc", "decode.hip")).read()
+    code = re.sub(r"//.*", "", src)
+    assert "__builtin_amdgcn_readfirstlane" not in code, "use fq_uniform(): the builtin's result is a signed int"
+    out = tmp_path / "decode.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    "-I" + os.path.join(ROOT, "include"), "-o", str(out), os.path.join(ROOT, "fqcomp28_amd", "csrc", "decode.hip")],
+                   check=True, capture_output=True, timeout=600)
+    lines = [ln.strip() for ln in out.read_text().splitlines()]
+    assert any(ln.startswith("s_lshl_b64") or ln.startswith("s_or_b64") for ln in lines), "the scalar window is gone?"
+    for i, ln in enumerate(lines):
+        m = re.match(r"s_ashr_i32 (s\d+), s\d+, 31$", ln)
+        if not m:
+            continue
+        hi = int(m.group(1)[1:])
+        # the sign word must not become the upper half of a 64-bit OR operand within the next few instructions
+        for nxt in lines[i + 1: i + 6]:
+            assert not re.match(r"s_or_b64 .*s\[%d:%d\]" % (hi - 1, hi), nxt), (ln, nxt)
+
+
 def test_product_library_has_no_experiment_switches():
     """The timing-experiment switches (FQGPU_DEBUG_*: kernels skipped, wrong output by design) live in
     the -DFQGPU_EXPERIMENTS build of tools/traffic_experiment.py only."""
