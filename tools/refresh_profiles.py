@@ -1,5 +1,6 @@
-"""Copies the rocprofv3 summaries of tools/profile_r02.sh (gpurun_out/r02_*) and the default bench
-line (gpurun_out/r2_bench_default.log) into profiles/ and prints the figures DESIGN.md quotes.
+"""Copies the rocprofv3 summaries of tools/profile_round.sh <tag> (gpurun_out/<tag>_*) and the default bench
+line (gpurun_out/<tag>_bench_default.log) into profiles/ and prints the figures DESIGN.md quotes.
+    python tools/refresh_profiles.py [tag, default r03]
 Everything is stamped with the commit it was measured on and with the hash of the device code
 (bench.py quotes `traffic` only while that hash is unchanged)."""
 import collections
@@ -16,7 +17,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
 sys.path.insert(0, R)
 import bench  # noqa: E402  (kernel_sources_sha)
 
-TAG = "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def newest(pat):
@@ -37,16 +38,16 @@ def last_json(path):
 SPAN_KERNELS = {
     "tile_hist2": ["k_tile_hist2"],
     "seq.scatter": ["k_tile_partition<SeqModel>"], "qual.scatter": ["k_tile_partition<QualModel>"],
-    "seq.setfunc": ["k_seq_setfunc<32u, true>"], "seq.chains": ["k_seq_emit"], "seq.resolve": ["k_seq_resolve"],
-    "qual.walk1": ["k_seg_walk<QualModel, 1>"], "qual.walk2": ["k_seg_walk<QualModel, 2>"],
-    "qual.setfunc": ["k_seg_setfunc<QualModel, 32u>"],
+    "seq.setfunc": ["k_seq_setfunc<32u, true>"], "seq.chains": ["k_seq_emit"], "seq.resolve": ["k_seq_resolve<32u>"],
+    "qual.stage1": ["k_seg_stage1<QualModel, 32u>"], "qual.heads": ["k_seg_heads<QualModel>"], "qual.walk2": ["k_seg_walk<QualModel, 2>"],
+    "qual.scan": ["k_seg_scan<QualModel>"],
     "seq.gatherpack": ["k_tile_gather_pack<SeqModel>"], "qual.gatherpack": ["k_tile_gather_pack<QualModel>"],
 }
 
 commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=R, capture_output=True, text=True).stdout.strip()
 sha = bench.kernel_sources_sha()
-f4 = newest(R + "gpurun_out/r02_prof4/**/*kernel_stats.csv")
-f1 = newest(R + "gpurun_out/r02_prof1/**/*kernel_stats.csv")
+f4 = newest(R + "gpurun_out/%s_" % TAG + "prof4/**/*kernel_stats.csv")
+f1 = newest(R + "gpurun_out/%s_" % TAG + "prof1/**/*kernel_stats.csv")
 s4, s1 = list(csv.DictReader(open(f4))), list(csv.DictReader(open(f1)))
 shutil.copy(f4, R + "profiles/%s_bench_encode_kernel_stats.csv" % TAG)
 shutil.copy(f1, R + "profiles/%s_encode_one_lane_kernel_stats.csv" % TAG)
@@ -66,8 +67,8 @@ def agg(path):
     return a
 
 
-fa = agg(newest(R + "gpurun_out/r02_pmc_f/**/*counter_collection.csv"))
-wa = agg(newest(R + "gpurun_out/r02_pmc_w/**/*counter_collection.csv"))
+fa = agg(newest(R + "gpurun_out/%s_" % TAG + "pmc_f/**/*counter_collection.csv"))
+wa = agg(newest(R + "gpurun_out/%s_" % TAG + "pmc_w/**/*counter_collection.csv"))
 skip = ("k_hist_", "k_build", "k_normalize", "k_fill", "k_log", "k_reset", "k_probe")
 out = []
 for n in sorted(fa, key=lambda k: -(fa[k][1] * 2 + wa.get(k, [0, 0])[1])):
@@ -99,7 +100,7 @@ json.dump({"commit": commit, "kernel_sources_sha": sha, "block_mib": 256, "block
                    "average launch times from the --kernel-trace --stats passes of the same commit"},
           open(R + "profiles/%s_traffic.json" % TAG, "w"), indent=1)
 
-sq = sorted(glob.glob(R + "gpurun_out/r02_pmc_sq/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+sq = sorted(glob.glob(R + "gpurun_out/%s_" % TAG + "pmc_sq/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
 if sq:
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
@@ -118,7 +119,7 @@ if sq:
                     100 * c["SQ_WAIT_INST_LDS"] / wc, 100 * c["SQ_ACTIVE_INST_ANY"] / wc, c["SQ_LDS_IDX_ACTIVE"],
                     100 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), c["SQ_BUSY_CYCLES"]))
 
-ins = sorted(glob.glob(R + "gpurun_out/r02_pmc_insts/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+ins = sorted(glob.glob(R + "gpurun_out/%s_" % TAG + "pmc_insts/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
 if ins:
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
@@ -135,12 +136,12 @@ if ins:
                 continue
             f.write("\"%s\",%d,%s\n" % (n, calls[n], ",".join("%.4g" % (c[k] / max(calls[n], 1)) for k in cols)))
 
-d = last_json(R + "gpurun_out/r2_bench_default.log")
+d = last_json(R + "gpurun_out/%s_bench_default.log" % TAG)
 json.dump(d, open(R + "profiles/%s_bench_default_line.json" % TAG, "w"), indent=1)
-e = last_json(R + "gpurun_out/r02_prof4.log")
+e = last_json(R + "gpurun_out/%s_" % TAG + "prof4.log")
 json.dump(e, open(R + "profiles/%s_bench_encode_line.json" % TAG, "w"), indent=1)
 box_sha = e.get("kernel_sources_sha")
 print("commit", commit, "kernel sources sha", sha, "(profiled box saw %s)" % box_sha)
 assert box_sha in (None, sha), "the profiles were taken on other device code than this checkout's"
-print("default:", d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], d["cpu_baseline"]["value"],
+print("default:", d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"].get("rocprof_avg_launch_ms"), d["cpu_baseline"]["value"],
       d["gpu_over_cpu_all_cores"], "rocprof run:", e["value"])
