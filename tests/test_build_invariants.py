@@ -56,6 +56,49 @@ def test_decode_walk_never_sign_extends_a_stream_word(tmp_path):
             assert not re.match(r"s_or_b64 .*s\[%d:%d\]" % (hi - 1, hi), nxt), (ln, nxt)
 
 
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_partition_ranking_loops_are_wave_uniform_straight_line_blocks(tmp_path):
+    """K3 (k_tile_partition) takes the rank of a symbol from ONE lane-ordered LDS atomic: right only if
+    iteration k of every lane precedes iteration k + 1 of any lane.  Round 2 found the failure mode as a
+    parity error: with a per-lane trip count hipcc's unrolling let low lanes run a group of iterations
+    ahead.  The property on the ISA: every loop that holds the ranking atomics is ONE basic block that
+    branches back on a SCALAR condition and never touches EXEC -- all lanes walk it together, the atomics
+    issue in program order -- with the G atomics of the hand-pipelined group in it (8 plain, 4 combining)."""
+    out = tmp_path / "encode.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    "-I" + os.path.join(ROOT, "include"), "-o", str(out), os.path.join(ROOT, "fqcomp28_amd", "csrc", "encode.hip")],
+                   check=True, capture_output=True, timeout=900)
+    lines = out.read_text().splitlines()
+    found = {}
+    for model in ("9QualModel", "8SeqModel"):
+        start = [i for i, ln in enumerate(lines) if ln.startswith("_ZN12_GLOBAL__N_116k_tile_partitionI" + model)][0]
+        end = next(i for i in range(start, len(lines)) if ".amdhsa_next_free_vgpr" in lines[i])
+        blocks, cur = [], []
+        for ln in lines[start:end]:
+            if re.match(r"^\.LBB\d+_\d+:", ln) or ln.startswith("; %bb."):
+                blocks.append(cur)
+                cur = [ln]
+            else:
+                cur.append(ln)
+        blocks.append(cur)
+        counts = []
+        for b in blocks:
+            n = sum("ds_add_rtn_u32" in ln for ln in b)
+            if not n:
+                continue
+            label = b[0].split(":")[0]
+            code = [ln.strip() for ln in b[1:] if ln.strip() and not ln.strip().startswith(";")]
+            back = [i for i, ln in enumerate(code) if ln in ("s_cbranch_scc0 " + label, "s_cbranch_scc1 " + label)]
+            assert back, (model, label, "the ranking loop does not branch back on a scalar condition")
+            code = code[: back[0] + 1]  # the loop: from its label to its back edge
+            assert sum("ds_add_rtn_u32" in ln for ln in code) == n
+            assert not [ln for ln in code if re.search(r"\bexec\b", ln)], (model, label, "EXEC is touched inside a ranking loop")
+            assert [ln for ln in code if ln.startswith("s_cbranch") or ln.startswith("s_branch")] == [code[-1]], (model, label)
+            counts.append(n)
+        found[model] = sorted(counts)
+    assert found == {"9QualModel": [4, 8], "8SeqModel": [4, 8]}, found
+
+
 def test_product_library_has_no_experiment_switches():
     """The timing-experiment switches (FQGPU_DEBUG_*: kernels skipped, wrong output by design) live in
     the -DFQGPU_EXPERIMENTS build of tools/traffic_experiment.py only."""

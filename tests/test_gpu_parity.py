@@ -364,6 +364,22 @@ def test_partition_fallback_without_lane_ordered_lds_atomics(F, golden_dir, monk
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_partition_fallback_at_bench_scale(F, monkeypatch, mode):
+    """The ballot-match partition (what a device without lane-ordered LDS atomics would run) on a block
+    of the size class the bench uses -- 96 MiB: 1 400 tiles, 22 tile groups, quality runs in every
+    context -- for BASELINE's reads and for binned qualities (one context holding half a tile)."""
+    big, brecs = _synth(F, mode, 96 << 20)
+    sample = brecs[brecs["qual_off"] < (32 << 20)]
+    sft, qft = F.freq_tables(big, sample)
+    monkeypatch.setenv("FQGPU_NO_LDS_ATOMIC_RANK", "1")
+    ctx = F.Context(sft, qft)
+    monkeypatch.delenv("FQGPU_NO_LDS_ATOMIC_RANK")
+    g = ctx.encode_block(big, brecs)
+    ctx.close()
+    assert_same_encoding(g, O.OracleCtx(sft, qft).encode(big, brecs))
+
+
 def _qual_ctx_of(raw, recs):
     """context of every quality symbol (numpy restatement of FSE_Quality::calcContext)."""
     out = []
