@@ -7,7 +7,7 @@
  * src/workspace.cpp:14-88).  It is the checker for the HIP path and the CPU
  * baseline of bench.py ("kind": "port"); nothing under fqcomp28_amd/ may call it.
  *
- * Parity status: the reference cannot be built here (its build fetches four
+ * Parity status: PARITY UNPINNED against the reference itself -- the reference cannot be built here (its build fetches four
  * repositories over the network) and holds no golden byte
  * vectors for this path (every test is a round-trip).  The zstd
  * primitives are pinned against libzstd.so.1 1.4.8; the model layer is pinned
