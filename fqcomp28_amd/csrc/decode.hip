@@ -278,17 +278,34 @@ struct WalkT {
     return v;
   }
   // entry of the context from what load(slot) returned; a pending entry is waited for
-  __device__ __forceinline__ uint32_t take(unsigned slot, uint2 e) const {
+  __device__ __forceinline__ uint32_t take(unsigned slot, uint2 &e) const {
     unsigned unused = 0;
     return take(slot, e, ~0u, unused);
   }
   // ... `left` = the slot the walk has just left: coming straight back to it is counted in `runs`
-  __device__ __forceinline__ uint32_t take(unsigned slot, uint2 e, unsigned left, unsigned &runs) const {
+#ifdef FQGPU_EXPERIMENTS
+  mutable unsigned n_pending = 0, n_self = 0;  // slow paths taken, self-following contexts among them
+  mutable unsigned long long t_pending = 0;     // shader clocks spent in them
+#endif
+  // (e.x is kept equal to the entry returned: the refill's address is worked out from the vector register)
+  __device__ __forceinline__ uint32_t take(unsigned slot, uint2 &e, unsigned left, unsigned &runs) const {
     uint32_t entry = fq_uniform(e.x);
     if (__builtin_expect(entry == FQ_ENTRY_PENDING, 0)) {
+#ifdef FQGPU_EXPERIMENTS
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      n_pending++;
+      n_self += slot == left;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      entry = fq_uniform(*entry_at(slot));
+      t_pending += __builtin_amdgcn_s_memtime() - t0;
+      runs += slot == left;
+      e.x = entry;
+      return entry;
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       entry = fq_uniform(*entry_at(slot));
       runs += slot == left;
+      e.x = entry;
     }
     return entry;
   }
@@ -315,6 +332,13 @@ __device__ __forceinline__ void walk_positions(WalkT<COMPACT> &wk, LdsBits &br, 
   uint2 e = wk.load(slot);
   uint32_t cur = wk.take(slot, e);
   wk.settle(toff);
+  // ebase = new state + table of the entry in hand, from the entry's own vector register: the upper half picked by
+  // the operand selector of one add (the scalar shift of `cur` and the shift of the bits become one shift-add with
+  // it); first thing behind the next entry's read, well in front of its use
+  unsigned ebase = 0;
+  auto set_ebase = [&] {
+    if (!COMPACT) ebase = (e.x >> 16) + e.y;  // (v_add_u32_sdwa ... src0_sel:WORD_1: the compiler's own choice once the entry counts as a vector value)
+  };
   unsigned keep = 0, acc = 0;
   // One symbol; j = its byte in acc.  ORDER IS THE POINT: the chain of a stream is entry -> symbol ->
   // next context -> LDS read of that context's entry, and a lone wave issues one instruction every four
@@ -346,6 +370,7 @@ __device__ __forceinline__ void walk_positions(WalkT<COMPACT> &wk, LdsBits &br, 
       h.push(s8);
       acc |= (s8 >> 3) << (8u * j);
       cur = wk.fetch((cur >> 16) + (bits << 2) + tbl_s);
+      e.x = cur;
       runs += 2;
       return;
     }
@@ -353,11 +378,16 @@ __device__ __forceinline__ void walk_positions(WalkT<COMPACT> &wk, LdsBits &br, 
     const uint2 ne = wk.load(nslot);
     uint32_t ntoff = wk.ask_table(nslot);
     __builtin_amdgcn_sched_barrier(0);
+    set_ebase();
     const unsigned nb = (cur >> 9) & 15u;
     const unsigned bits = br.read(nb, (j & 1u) != 0 || tail);
     h.push(s8);
     // (e.y, the table's byte offset, stays in its vector register; COMPACT: the state-0 entry is word dt_off + 1)
-    const unsigned off = COMPACT ? (cur >> 16) + ((bits + (toff + 1u)) << 2) : (bits << 2) + ((cur >> 16) + e.y);
+    unsigned off;
+    if (COMPACT) off = (cur >> 16) + ((bits + (toff + 1u)) << 2);
+    else {
+      off = (bits << 2) + ebase;
+    }
     acc |= (s8 >> 3) << (8u * j);
     wk.refill(slot, off);
     const unsigned left = slot;
@@ -373,22 +403,31 @@ __device__ __forceinline__ void walk_positions(WalkT<COMPACT> &wk, LdsBits &br, 
   unsigned g = 0;  // symbols done
   auto group_done = [&] {
     const unsigned kslot = (g >> 2) & 63u;
-    keep = lane == kslot ? fq_sym_bytes<M>(acc) : keep;
-    if (kslot == 63u) *reinterpret_cast<FQ_GLOBAL uint32_t *>(o + (g - 252u) + 4u * lane) = keep;  // (reads start anywhere: unaligned dwords)
+    // lane kslot of keep <- the four bytes (two instructions; compare, move, wait state and select are four)
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(keep) : "s"(fq_uniform(fq_sym_bytes<M>(acc))), "s"(fq_uniform(kslot)));
+    if (__builtin_expect(kslot == 63u, 0)) *reinterpret_cast<FQ_GLOBAL uint32_t *>(o + (g - 252u) + 4u * lane) = keep;  // (reads start anywhere: unaligned dwords)
   };
-  while (g + 4 <= n) {
-    for (runs = 0; g + 4 <= n && runs < 2; g += 4) {  // the plain form, until a group meets two such contexts
+  const unsigned n4 = n & ~3u;
+  // (one loop condition: the switch of forms moves the loop's end -- `stop` -- to where the walk stands)
+  while (g < n4) {
+    for (unsigned stop = n4; g < stop;) {  // the plain form, until a group meets two such contexts
       acc = 0;
       runs = 0;
       step(0, std::false_type()); step(1, std::false_type()); step(2, std::false_type()); step(3, std::false_type());
       group_done();
+      g += 4;
+      stop = runs >= 2 ? g : n4;
+      asm volatile("" : "+s"(stop));  // (kept a number: the compiler would make two lane masks and their conjunction of it again)
     }
-    if (g + 4 <= n) tbl_s = COMPACT ? (toff + 1u) << 2 : fq_uniform(e.y);
-    for (; g + 4 <= n && runs >= 2; g += 4) {  // the form for runs, as long as every group has one
+    if (g < n4) tbl_s = COMPACT ? (toff + 1u) << 2 : fq_uniform(e.y);
+    for (unsigned stop = n4; g < stop;) {  // the form for runs, as long as every group has one
       acc = 0;
       runs = 0;
       step(0, std::true_type()); step(1, std::true_type()); step(2, std::true_type()); step(3, std::true_type());
       group_done();
+      g += 4;
+      stop = runs >= 2 ? n4 : g;
+      asm volatile("" : "+s"(stop));
     }
   }
   const unsigned r = n - g;  // < 4 symbols left
@@ -456,6 +495,12 @@ __device__ void decode_stream(const DecJob &j, const TabView &tab, typename Walk
     if (br.pos() != 0) res->corrupt = 1;
     res->total_bits = (unsigned long long)(p0 - (long long)sum_logs);
   }
+#ifdef FQGPU_EXPERIMENTS
+  // (make experiments: how often the walk finds an entry pending, and what that costs)
+  if (lane == 0 && !COMPACT)
+    printf("walk stats stream %d: %u records, entries found pending %u (the context following itself: %u), shader clocks in the slow path %llu\n",
+           (int)M::STREAM, j.n_recs, wk.n_pending, wk.n_self, wk.t_pending);
+#endif
 }
 
 // One stride of one stream, started from a snapshot of the decode index (or from the end of the
