@@ -257,7 +257,8 @@ struct WalkT {
   // one behind it, is still on its way -- the mark has landed.  (COMPACT: the scalar load asked for
   // in between may return out of order: lgkmcnt(0).)
   // M0 is not restored and cannot be declared clobbered (hipcc: "reserved register"): nothing else in these
-  // kernels uses it -- no other LDS-DMA, no movrel -- which tests/test_build_invariants.py checks on the ISA.
+  // kernels uses it but the walk's v_writelane, which sets it itself -- no other LDS-DMA, no movrel --, which
+  // tests/test_build_invariants.py checks on the ISA.
   // EXEC is set back to all ones, not restored: the walk runs with the full wave (decode_stream / decode_chunk
   // check that on entry and refuse to run otherwise).
   __device__ __forceinline__ void refill(unsigned slot, unsigned off) const {

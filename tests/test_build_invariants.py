@@ -12,19 +12,27 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_decode_walk_owns_m0_and_has_no_scratch(tmp_path):
-    """The LDS-DMA refill of the decode walk (decode.hip, WalkT::refill) sets M0 from inline assembly
-    and does not restore it, and it sets EXEC to -1 behind the load: valid as long as the compiler
-    itself never uses M0 in those kernels and nothing spills.  If a toolchain change breaks that,
+    """The LDS-DMA refill of the decode walk (decode.hip, WalkT::refill) and the v_writelane that collects
+    the output set M0 from inline assembly and do not restore it, and the refill sets EXEC to -1 behind
+    the load: valid as long as the compiler itself never uses M0 in those kernels and nothing spills.  If a toolchain change breaks that,
     this test says so before a GPU does."""
     out = tmp_path / "decode.s"
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                     "-I" + os.path.join(ROOT, "include"), "-o", str(out), os.path.join(ROOT, "fqcomp28_amd", "csrc", "decode.hip")],
                    check=True, capture_output=True, timeout=600)
     text = out.read_text()
-    m0 = [ln.strip() for ln in text.splitlines() if re.search(r"\bm0\b", ln) and not ln.lstrip().startswith(";")]
+    lines = [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.lstrip().startswith(";")]
+    m0 = [ln for ln in lines if re.search(r"\bm0\b", ln)]
     assert m0, "the refill is gone?"
-    foreign = [ln for ln in m0 if not re.fullmatch(r"s_mov_b32 m0, s\d+", ln)]
+    # the two users of M0 are the walk's own assembly blocks, and each sets M0 itself right in front of its use:
+    # the refill (s_mov m0 .. global_load_lds_dword) and the output dword's v_writelane (lane select in M0)
+    foreign = [ln for ln in m0 if not re.fullmatch(r"s_mov_b32 m0, s\d+", ln) and not re.fullmatch(r"v_writelane_b32 v\d+, s\d+, m0", ln)]
     assert not foreign, foreign[:5]
+    for i, ln in enumerate(lines):
+        if ln.startswith("global_load_lds_dword"):
+            assert any(re.fullmatch(r"s_mov_b32 m0, s\d+", p) for p in lines[i - 3:i]), lines[i - 4:i + 1]
+        if ln.startswith("v_writelane_b32") and ln.endswith("m0"):
+            assert re.fullmatch(r"s_mov_b32 m0, s\d+", lines[i - 1]), lines[i - 2:i + 1]
     assert "global_load_lds_dword" in text
     assert "scratch_" not in text
 
