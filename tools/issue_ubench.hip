@@ -66,6 +66,10 @@ __global__ void __launch_bounds__(64) k(unsigned iters, unsigned *out, unsigned 
     if (VAR == 33) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_write_b32 %9, %5\n\tds_read2_b32 v[10:11], v12 offset1:1\n\t" TWELVE "v_mov_b32 v13, 0\n\tds_write2_b64 v13, v[16:17], v[18:19] offset0:128 offset1:129\n\t" "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, v10");
     if (VAR == 34) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_write_b32 %9, %5\n\tds_read2_b32 v[10:11], v12 offset1:1\n\tv_mov_b32 v13, 0\n\tds_write_b128 v13, v[16:19] offset:1024\n\t" TWELVE "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, v10");
     if (VAR == 35) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tv_mov_b32 v13, 0\n\tds_write_b128 v13, v[16:19] offset:1024\n\tds_write_b32 %9, %5\n\tds_read2_b32 v[10:11], v12 offset1:1\n\t" TWELVE "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, v10");
+    if (VAR == 36) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_write_b32 %9, %5\n\tds_read_b32 v10, v12\n\t" TWELVE "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, v10");
+    if (VAR == 37) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_write_b32 %9, %5\n\tds_read_b64 v[10:11], v12\n\t" TWELVE "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, v10");
+    if (VAR == 38) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_write_b32 %9, %5\n\tds_read_b32 v10, v12\n\tds_read_b32 v11, v12 offset:4\n\t" TWELVE "s_waitcnt lgkmcnt(1)\n\tv_readfirstlane_b32 %1, v10");
+    if (VAR == 39) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_read2_b32 v[10:11], v12 offset1:1\n\t" TWELVE "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, v10");
     if (VAR == 19) MEMBODY(TWELVE "s_mov_b32 m0, %8\n\ts_mov_b64 exec, 1\n\tglobal_load_dword v12, %9, %7\n\ts_mov_b64 exec, -1");  // a plain load instead of the LDS-DMA
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -184,6 +188,10 @@ int main() {
     run<33>("33 chain + ds_write2_b64 (21 per 16)", grid);
     run<34>("34 chain + b128 right behind the entry read (21 per 16)", grid);
     run<35>("35 chain + b128 in front of mark and read (21 per 16)", grid);
+    run<36>("36 chain (28) with ds_read_b32", grid);
+    run<37>("37 chain (28) with ds_read_b64", grid);
+    run<38>("38 chain (28) with two ds_read_b32, the wait for the first only (20 per 16)", grid);
+    run<39>("39 chain (28) without the mark (18 per 16)", grid);
     run<22>("22 12 s_add + far refills, no ds ops (18 per 16)", grid);
   }
   run2<0>("two waves: walker skeleton alone");
