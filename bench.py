@@ -396,7 +396,7 @@ def main():
                                     "lanes": 2 * len(dblocks), "ns_per_symbol_per_lane": round(d_ms * 1e6 / max(1, max(int(r["len"].sum()) for _, r in blocks)), 1),
                                     "traffic": None,
                                     "limit": "not bytes: the format leaves one serial chain per (block, stream); one wave walks it and is "
-                                             "bound by the chain of a symbol (nine instructions and an LDS round trip) and by its own instruction issue, 34 instructions per symbol (DESIGN.md section 5)"}
+                                             "bound by the chain of a symbol (nine instructions and an LDS round trip) and by its own instruction issue, 31 instructions per symbol (DESIGN.md section 5)"}
         # extension: the same blocks coded with a decode index (identical streams + a sidecar of
         # snapshots every --index-stride symbols), decoded with one lane per (stream, stride)
         ctx.set_index_stride(args.index_stride)
