@@ -251,3 +251,69 @@ def test_quality_lines_that_look_like_headers_do_not_move_a_chunk_end(tool, tmp_
         r = subprocess.run([tool, "chunks", path, str(size)], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout
         assert [int(ln.split()[2]) for ln in r.stdout.splitlines() if ln.startswith("chunk ")] == reference_chunks(raw, table, size)
+
+
+# ---------------------------------------------------------------- the same host code under sanitizers
+@pytest.fixture(scope="module")
+def tool_sanitized(tmp_path_factory):
+    """archive_tool with AddressSanitizer and UBSan over the header-only host code it instantiates (archive.hpp,
+    workspace.hpp, headers.hpp); libfqgpu.so itself is loaded as it is.  (GPU sanitizers do not exist on this pool.)"""
+    exe = str(tmp_path_factory.mktemp("arc_san") / "archive_tool_san")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                        os.path.join(ROOT, "tests", "cpp", "archive_tool.cpp"), "-L" + os.path.join(ROOT, "fqcomp28_amd"), "-lfqgpu",
+                        "-Wl,-rpath," + os.path.join(ROOT, "fqcomp28_amd"), "-lpthread"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here: " + r.stderr[-200:])
+    return exe
+
+
+def test_container_reader_and_writer_are_clean_under_asan_and_ubsan(F, tool, tool_sanitized, tmp_path, golden_dir):
+    """Every path of the container code the other tests walk -- copy (readBlock / writeBlock / writeIndex), dump (misc
+    streams and header decoding), the reader's backwards boundary search at awkward reading sizes, the writer fed
+    last chunk first, a truncated archive -- once more with the sanitizers on: same output, no report."""
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+
+    def run(exe, *args):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, env=env)
+        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+        return r
+
+    for name in FIXTURES:
+        path = os.path.join(golden_dir, name + ".fastq")
+        raw, recs = O.load_fastq(path)
+        n_blocks = 1 if len(recs) < 10 else 4
+        src = str(tmp_path / (name + ".fqc"))
+        oracle_archive(F, src, raw, recs, n_blocks, order=list(reversed(range(n_blocks))))
+        dst = str(tmp_path / (name + ".copy.fqc"))
+        r = run(tool_sanitized, "copy", src, dst)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert run(tool_sanitized, "dump", src).stdout == run(tool, "dump", src).stdout  # (blocks in completion order, index unsorted)
+        assert run(tool_sanitized, "dump", dst).stdout == run(tool, "dump", dst).stdout
+        biggest = int((np.diff(np.concatenate([[0], recs["qual_off"].astype(np.int64) + recs["len"] + 1]))).max())
+        for size in (biggest, biggest + 1, 1777, raw.size - 1, raw.size + 10):
+            if size < biggest:
+                continue
+            assert run(tool_sanitized, "chunks", path, str(size)).stdout == run(tool, "chunks", path, str(size)).stdout
+        back = str(tmp_path / (name + ".back.fastq"))
+        assert run(tool_sanitized, "rejoin", path, back, str(biggest + 7)).returncode == 0
+        assert open(back, "rb").read() == raw.tobytes()
+        # a reading size below one record and a truncated archive: refused, cleanly
+        assert run(tool_sanitized, "chunks", path, str(biggest // 2)).returncode == 1
+        whole = open(src, "rb").read()
+        cut = str(tmp_path / (name + ".cut.fqc"))
+        open(cut, "wb").write(whole[: len(whole) // 2])
+        assert run(tool_sanitized, "dump", cut).returncode == 1
+
+
+def test_misc_coder_decodes_or_refuses_damaged_streams_under_asan_and_ubsan(tmp_path):
+    """tests/cpp/misc_fuzz.cpp: fq_misc.cpp compiled with the sanitizers; round trips of the container's stream
+    shapes, then thousands of truncated / bit-flipped / random streams into exact-size buffers."""
+    exe = str(tmp_path / "misc_fuzz")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        os.path.join(ROOT, "tests", "cpp", "misc_fuzz.cpp"), os.path.join(ROOT, "fqcomp28_amd", "csrc", "fq_misc.cpp"),
+                        "-I" + os.path.join(ROOT, "include"), "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here: " + r.stderr[-200:])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stdout + r.stderr[-2000:]
+    assert "no report" in r.stdout
