@@ -15,9 +15,16 @@ import headers_oracle as HO  # noqa: E402
 
 @pytest.fixture(scope="module")
 def tool(tmp_path_factory):
+    """headers_tool over headers.hpp, built with AddressSanitizer and UBSan when g++ has their runtime here (every
+    test below then doubles as a memory / undefined-behaviour check of the tokeniser and the field coder: a report
+    ends the tool with a code no test expects), plainly otherwise."""
     exe = str(tmp_path_factory.mktemp("hdr") / "headers_tool")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-o", exe,
-                    os.path.join(ROOT, "tests", "cpp", "headers_tool.cpp")], check=True)
+    src = os.path.join(ROOT, "tests", "cpp", "headers_tool.cpp")
+    san = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Werror", "-fsanitize=address,undefined",
+                          "-fno-sanitize-recover=undefined", "-o", exe, src], capture_output=True)
+    if san.returncode != 0:
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-o", exe, src], check=True)
+    os.environ.setdefault("ASAN_OPTIONS", "detect_leaks=0")
     return exe
 
 
