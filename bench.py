@@ -7,12 +7,13 @@ A step = one pass of the hot path over one batch: every block of the workload is
 N = 1   BASELINE.json configs[1]: 1 GiB of synthetic 150 bp reads (uniform ACGT, Phred ~ N(34,5)
         clipped to [2,41]), reference default block size -R 256 (4 blocks of 256 MiB), frequency
         tables from the first 128 MiB.
-N > 1   BASELINE.json configs[2]: the SAME 1 GiB job cut into 64 MiB blocks (16 of them), block b
-        coded by rank b mod N (strong scaling: total work fixed); one sample's tables, computed by
-        rank 0 and broadcast as bytes.  One process per GPU; blocks are independent, so there is no
-        data-path collective and no RCCL call anywhere: the table broadcast, the barriers and the
-        max-over-ranks of the elapsed time go over gloo.  `--layout weak` gives every rank its own
-        1 GiB instead.
+N > 1   the same on every GPU (weak scaling: the work per GPU is fixed): rank r codes its own 1 GiB of
+        reads (4 blocks of 256 MiB, own seed) with ONE sample's tables, computed by rank 0 and broadcast
+        as bytes -- the units (blocks) are independent given the tables and are sharded over the ranks.
+        One process per GPU; no data-path collective and no RCCL call anywhere: the table broadcast, the
+        barriers and the max-over-ranks of the elapsed time go over gloo.  `--layout strong` is
+        BASELINE.json configs[2] instead: ONE 1 GiB job cut into 64 MiB blocks (16 of them), block b
+        coded by rank b mod N (total work fixed: two blocks per GPU at N = 8).
 value = raw FASTQ bytes all ranks coded per second (max-over-ranks time).  After the timed region
 (not part of `value`): a whole timed block is byte-compared with the CPU oracle (also the source of
 `ratio_vs_reference`), decode of the same archive (configs[4]: blocks dealt over the N ranks), the
@@ -185,7 +186,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layout", default="auto", choices=["auto", "config1", "strong", "weak"],
-                    help="auto: configs[1] at N=1, configs[2] (strong scaling of one 1 GiB job in 64 MiB blocks) at N>1")
+                    help="auto: configs[1] at N=1 and on every GPU at N>1 (weak); strong: configs[2], one 1 GiB job in 64 MiB blocks dealt over the ranks")
     ap.add_argument("--mib", type=int, default=1024, help="raw FASTQ of the job (weak layout: per GPU)")
     ap.add_argument("--block-mib", type=int, default=None, help="-R of the reference (default 256; 64 in the strong layout)")
     ap.add_argument("--sample-mib", type=int, default=128, help="-S of the reference")
@@ -215,7 +216,7 @@ def main():
     import fqcomp28_amd as F
     assert F.device_count() > local, "bench.py needs a GPU (no CPU fallback)"
     device = local
-    layout = args.layout if args.layout != "auto" else ("config1" if world == 1 else "strong")
+    layout = args.layout if args.layout != "auto" else ("config1" if world == 1 else "weak")
     block_mib = args.block_mib or (64 if layout == "strong" else 256)
 
     def barrier():
@@ -235,7 +236,13 @@ def main():
         del job
     else:
         blocks = make_workload(F, args.mib << 20, block_mib << 20, seed=28 + (rank if layout == "weak" else 0))
-        sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
+        if layout == "weak" and world > 1:  # one job, one sample: rank 0's tables for every rank (src/archive.cpp:17-24 analyses one sample)
+            sft = qft = None
+            if rank == 0:
+                sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
+            sft, qft = farm.broadcast_tables(sft, qft, dist)
+        else:
+            sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
         job_blocks = len(blocks) * world
     ctx = F.Context(sft, qft, device=device)
     ctx.set_lanes(max(1, min(args.lanes, 8)))
@@ -554,7 +561,8 @@ def main():
         cfg_name = {"config1": "BASELINE configs[1]: %d MiB synthetic 150 bp reads" % args.mib,
                     "strong": "BASELINE configs[2]: ONE job of %d MiB synthetic 150 bp reads in %d MiB blocks dealt round-robin over %d GPU(s)"
                               % (args.mib, block_mib, world),
-                    "weak": "BASELINE configs[1] per GPU (weak scaling): %d MiB/GPU synthetic 150 bp reads" % args.mib}[layout]
+                    "weak": "BASELINE configs[1] on each of %d GPU(s) (weak scaling: rank r codes its own %d MiB of synthetic 150 bp reads, one sample's tables from rank 0)"
+                            % (world, args.mib)}[layout]
         line = {
             "metric": "encode MB/s (raw FASTQ in)", "value": round(enc_MBps, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -564,7 +572,8 @@ def main():
                                    "inputs resident in HBM" % (cfg_name, block_mib, args.sample_mib),
                        "layout": layout, "job_blocks": job_blocks, "blocks_this_gpu": len(blocks),
                        "records_this_gpu": n_recs, "bases_this_gpu": n_bases,
-                       "parallelism": "block b -> rank b mod %d, one process per GPU, tables broadcast over gloo, no data-path collective, no RCCL" % world},
+                       "parallelism": ("block b -> rank b mod %d" % world if layout == "strong" else "every rank its own blocks (%d ranks)" % world)
+                                      + ", one process per GPU, tables broadcast over gloo, no data-path collective, no RCCL"},
             "compressed": {"seq_bytes": seq_bytes, "qual_bytes": qual_bytes, "n_pos_bytes": npos_bytes,
                            "ratio_vs_reference": (round(check["gpu_bytes"] / check["oracle_bytes"], 6) if check else None),
                            "ratio_vs_reference_from": "seq+qual bytes of one whole timed block / the CPU oracle's bytes for the same block and tables",
