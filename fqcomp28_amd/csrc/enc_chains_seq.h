@@ -538,7 +538,10 @@ k_seq_resolve(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ lo
   for (unsigned item = threadIdx.x; item < n_items; item += SEQ_RESOLVE_THREADS) {
     const unsigned ic = seq_item_ctx(citem, item);
     const unsigned ins = seg[ic + 1] - seg[ic], inf = ins ? ins - 1 : 0, iQ = seq_group_of(inf, qmax, gmin);
-    const unsigned s_begin = (item - citem[ic]) * SEQ_ITEM_GROUPS * iQ, s_end = min(s_begin + SEQ_ITEM_GROUPS * iQ, ins);
+    // (the chain's LAST segment has no function of its own and belongs to no group: when the functions fill the
+    // last item's 64 groups exactly, s_begin + 64 * iQ stops one segment short of it -- the last item runs to the end)
+    const unsigned s_begin = (item - citem[ic]) * SEQ_ITEM_GROUPS * iQ;
+    const unsigned s_end = item + 1 == citem[ic + 1] ? ins : min(s_begin + SEQ_ITEM_GROUPS * iQ, ins);
     const unsigned xo = __hip_atomic_load(&item_entry[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     (void)seq_resolve_groups(fseg, seg, fbuf, fstride, ic, iQ, inf, ins, s_begin, s_end, xo, entry);
   }

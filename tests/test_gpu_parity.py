@@ -480,6 +480,40 @@ def test_sequence_segment_functions_are_exact(F, bases, segment):
     ctx.close()
 
 
+def test_long_sequence_chain_whose_functions_fill_its_last_item_exactly(F):
+    """One context holding the block, with a number of segments such that its segment functions (all segments but
+    the last) fill the 64-group items of the three-level resolve EXACTLY: the chain's last segment then lies
+    behind the last item's groups.  (Found by tools/soak_roundtrip.py in round 3: the expand step stopped at the
+    end of the last group and left that segment's entry state as the scratch buffer had it -- two bytes of the
+    state flush wrong, or right by luck of what the buffer held; hence one handle for all sizes here.)
+    Constant reads (every base A): context AAAA has 146 of a read's 150 symbols."""
+    raw, recs = _synth(F, 5, 3 << 20)
+    assert len(recs) >= 7192
+    head = int(recs[999]["qual_off"] + recs[999]["len"] + 1)
+    _, _, sft, qft = O.freq_tables(raw[:head], recs[:1000])
+    octx = O.OracleCtx(sft, qft)
+    for params, counts in (({"seq_segment": 1024, "seq_group": 4}, list(range(3588, 3600)) + list(range(5384, 5396))),   # 512 / 768 functions in groups of 4
+                           ({}, list(range(7180, 7192)))):                                                        # the sizes the soak tripped over
+        ctx = F.Context(sft, qft)
+        ctx.set_lanes(1)
+        if params:
+            ctx.set_chain_params(0, **params)
+        for n_recs in counts:
+            end = int(recs[n_recs - 1]["qual_off"] + recs[n_recs - 1]["len"] + 1)
+            braw, brecs = raw[:end], recs[:n_recs]
+            e = octx.encode(braw, brecs)
+            b = ctx.dblock(braw, brecs)
+            b.encode()
+            ctx.sync()
+            assert b.status()[0] == e["rc"] == 0
+            g = b.fetch()
+            for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+                assert np.array_equal(g[k], e[k]), (params, n_recs, k)
+            b.close()
+        ctx.close()
+    octx.close()
+
+
 def test_constant_phred0_qualities_fill_whole_tiles_with_one_context(F):
     """All qualities '!' (Phred 0): calcContext(0, 0, 0) for EVERY position, the read starts
     included, so whole 65536-symbol tiles hold one context -- the one input on which K1's 16-bit
