@@ -1016,3 +1016,16 @@ def test_gpu_parser_matches_cpu_parser(F, golden_dir):
             ctx.dblock(np.frombuffer(bad, dtype=np.uint8))
         assert ei.value.code in (-4, -2)
     ctx.close()
+
+
+def test_soak_sample_random_sizes_kinds_tables_parameters_and_call_paths():
+    """Forty cases of tools/soak_roundtrip.py (the sweep that found round 3's resolve bug runs thousands): random block
+    sizes, data kinds with runs and alternations written into the qualities, own or foreign tables, chain parameters
+    off their defaults, decode index, device-resident / host-pointer / unparsed-chunk calls, several blocks in flight
+    -- every case byte for byte against the oracle, both directions."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_roundtrip.py"), "40", "424242"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "soak: 40 cases" in r.stdout

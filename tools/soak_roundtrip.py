@@ -2,8 +2,9 @@
 Per case: synthetic reads (fqgpu_synth_fastq modes 2..5, some with their qualities rewritten into runs and
 alternations -- the contexts that come back at distance 0, 1, 2 are the decode walk's slow paths), tables from the
 block itself or from another block (foreign tables: escapes and rare symbols), encode -> five streams byte-equal to
-the oracle's -> decode of the ORACLE's streams -> raw block byte-equal.  Blocks are decoded alone and in batches
-(batches of many small blocks take the walk's compact form).
+the oracle's -> decode of the ORACLE's streams -> raw block byte-equal.  A third of the cases move the chain stage's
+segment lengths and group sizes off their defaults, a third code a decode index and decode through it; the block goes
+through the device-resident calls, the host-pointer call or, unparsed, through the GPU's record finder.
     python tools/soak_roundtrip.py [cases, default 60] [first seed]"""
 import os
 import sys
@@ -39,12 +40,55 @@ def rewrite_qualities(raw, recs, rng, how):
     return raw
 
 
+def several_blocks_in_flight(case, seed):
+    """2 .. 6 blocks of different sizes and kinds on ONE handle, encoded without waiting in between (each takes the
+    next encode lane), then decoded in one batch: every block against the oracle."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for k in range(int(rng.integers(2, 7))):
+        mode = int(rng.choice([2, 3, 4, 5]))
+        raw, _ = F.synth_fastq(int(rng.integers(3000, 2 << 20)), mode, seed=seed + 31 * k)
+        parts.append((raw, F.parse_fastq(raw)))
+    _, _, sft, qft = O.freq_tables(*parts[int(rng.integers(0, len(parts)))])
+    ctx = F.Context(sft, qft)
+    ctx.set_lanes(int(rng.integers(1, 9)))
+    octx = O.OracleCtx(sft, qft)
+    blocks = [ctx.dblock(raw, recs) for raw, recs in parts]
+    for b in blocks:
+        b.encode()
+    ctx.sync()
+    good = []
+    for b, (raw, recs) in zip(blocks, parts):
+        e = octx.encode(raw, recs)
+        rc = b.status()[0]
+        assert rc == e["rc"], (case, "several", rc, e["rc"])
+        if rc == 0:
+            g = b.fetch()
+            for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+                assert np.array_equal(g[k], e[k]), (case, "several", k)
+            b.wipe()
+            good.append((b, raw))
+    if good:
+        ctx.decode_dblocks([b for b, _ in good])
+        ctx.sync()
+        for b, raw in good:
+            assert b.status()[0] == 0 and np.array_equal(b.fetch_raw(), raw), (case, "several", "decode")
+    for b in blocks:
+        b.close()
+    octx.close()
+    ctx.close()
+    return len(good)
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t0 = time.time()
     done = 0
     for case in range(cases):
+        if case % 5 == 4:
+            done += several_blocks_in_flight(case, seed0 + case) > 0
+            continue
         rng = np.random.default_rng(seed0 + case)
         mode = int(rng.choice([2, 2, 3, 4, 4, 5]))
         size = int(rng.integers(3000, 3 << 20))
@@ -62,24 +106,50 @@ def main():
             _, _, sft, qft = O.freq_tables(raw, recs)
         ctx = F.Context(sft, qft)
         ctx.set_lanes(int(rng.integers(1, 5)))
+        # chain parameters off their defaults in a third of the cases: segment lengths and group sizes move every
+        # boundary of the chain stage (segments per chain, groups per item, items per chain)
+        if rng.random() < 0.35:
+            ctx.set_chain_params(int(rng.choice([0, 1024, 2048, 4096])), seq_generic=bool(rng.random() < 0.2),
+                                 seq_segment=int(rng.choice([1024, 2048, 4096])), seq_group=int(rng.choice([1, 2, 4, 8, 16])))
+        with_index = rng.random() < 0.3
+        if with_index:
+            ctx.set_index_stride(int(rng.choice([1, 2, 4])) << 16)
         octx = O.OracleCtx(sft, qft)
         e = octx.encode(raw, recs)
-        b = ctx.dblock(raw, recs)
-        b.encode()
-        ctx.sync()
-        rc = b.status()[0]
-        assert rc == e["rc"], (case, rc, e["rc"])
-        if rc == 0:
-            g = b.fetch()
-            for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
-                assert np.array_equal(g[k], e[k]), (case, mode, how, k)
-            b.load_streams(e["seq"], e["qual"], e["n_count"], e["n_pos"])
-            b.wipe()
-            ctx.decode_dblocks([b])
+        path = int(rng.integers(0, 3))  # 0: device-resident block, 1: host-pointer call, 2: unparsed chunk (GPU parser)
+        if path == 0:
+            b = ctx.dblock(raw, recs)
+            b.encode(flags=F.F_DECODE_INDEX if with_index else 0)
             ctx.sync()
-            assert b.status()[0] == 0 and np.array_equal(b.fetch_raw(), raw), (case, mode, how, "decode")
+            rc = b.status()[0]
+            g = b.fetch() if rc == 0 else None
+        else:
+            g = ctx.encode_block(raw, recs) if path == 1 else ctx.encode_raw(raw)
+            rc = g["rc"]
+            b = None
+        assert rc == e["rc"], (case, path, rc, e["rc"])
+        if rc == 0:
+            for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+                assert np.array_equal(g[k], e[k]), (case, mode, how, path, k)
+            if path == 2:
+                assert np.array_equal(g["recs"], recs), (case, "record table of the GPU parser")
+            if b is not None:
+                # decode of the ORACLE's streams (with this block's own index when it has one: the index belongs to
+                # the streams, which are the oracle's byte for byte)
+                idx = [b.fetch_index(0), b.fetch_index(1)] if with_index else None
+                b.load_streams(e["seq"], e["qual"], e["n_count"], e["n_pos"])
+                if idx:
+                    assert b.load_index(0, idx[0]) == 0 and b.load_index(1, idx[1]) == 0
+                b.wipe()
+                ctx.decode_dblocks([b])
+                ctx.sync()
+                assert b.status()[0] == 0 and np.array_equal(b.fetch_raw(), raw), (case, mode, how, "decode", with_index)
+            else:
+                rc, out = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, O.blank_skeleton(raw, recs))
+                assert rc == 0 and np.array_equal(out, raw), (case, mode, how, "decode_block")
             done += 1
-        b.close()
+        if b is not None:
+            b.close()
         octx.close()
         ctx.close()
         if case % 10 == 9:
