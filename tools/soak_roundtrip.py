@@ -4,7 +4,8 @@ alternations -- the contexts that come back at distance 0, 1, 2 are the decode w
 block itself or from another block (foreign tables: escapes and rare symbols), encode -> five streams byte-equal to
 the oracle's -> decode of the ORACLE's streams -> raw block byte-equal.  A third of the cases move the chain stage's
 segment lengths and group sizes off their defaults, a third code a decode index and decode through it; the block goes
-through the device-resident calls, the host-pointer call or, unparsed, through the GPU's record finder.
+through the device-resident calls, the host-pointer call or, unparsed, through the GPU's record finder; behind the
+host-pointer calls the oracle's streams are damaged (bit flips, truncation, random bytes) and decoded by both.
     python tools/soak_roundtrip.py [cases, default 60] [first seed]"""
 import os
 import sys
@@ -84,7 +85,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t0 = time.time()
-    done = 0
+    done = damaged = 0
     for case in range(cases):
         if case % 5 == 4:
             done += several_blocks_in_flight(case, seed0 + case) > 0
@@ -145,8 +146,30 @@ def main():
                 ctx.sync()
                 assert b.status()[0] == 0 and np.array_equal(b.fetch_raw(), raw), (case, mode, how, "decode", with_index)
             else:
-                rc, out = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, O.blank_skeleton(raw, recs))
+                skel = O.blank_skeleton(raw, recs)
+                rc, out = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, skel)
                 assert rc == 0 and np.array_equal(out, raw), (case, mode, how, "decode_block")
+                # damaged streams: the verdict is the oracle's -- refused by both, or accepted by both with the same bytes
+                for _ in range(3):
+                    sq, ql = e["seq"].copy(), e["qual"].copy()
+                    victim = sq if rng.random() < 0.5 else ql
+                    kind = int(rng.integers(0, 3))
+                    if kind == 0 and victim.size:
+                        victim[int(rng.integers(0, victim.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                    elif kind == 1 and victim.size > 4:
+                        cut = int(rng.integers(1, min(victim.size - 1, 64)))
+                        if victim is sq: sq = sq[:-cut]
+                        else: ql = ql[:-cut]
+                    elif victim.size:
+                        victim[int(rng.integers(0, victim.size))] = np.uint8(rng.integers(0, 256))
+                    orc, oout = octx.decode(sq, ql, e["n_count"], e["n_pos"], recs, skel)
+                    grc, gout = ctx.decode_block(sq, ql, e["n_count"], e["n_pos"], recs, skel)
+                    assert (grc == 0) == (orc == 0), (case, "damaged", kind, grc, orc)
+                    if grc == 0:
+                        assert np.array_equal(gout, oout), (case, "damaged", kind, "accepted by both, different bytes")
+                    else:
+                        assert grc == -3, (case, "damaged", grc)
+                    damaged += 1
             done += 1
         if b is not None:
             b.close()
@@ -154,7 +177,7 @@ def main():
         ctx.close()
         if case % 10 == 9:
             print("case %d of %d, %d round trips, %.0f s" % (case + 1, cases, done, time.time() - t0), flush=True)
-    print("soak: %d cases, %d encoded and decoded byte-exactly, the rest refused by both coders alike" % (cases, done))
+    print("soak: %d cases, %d encoded and decoded byte-exactly, the rest refused by both coders alike; %d damaged streams decoded with the oracle's verdict" % (cases, done, damaged))
 
 
 if __name__ == "__main__":
