@@ -6,7 +6,7 @@ the oracle's -> decode of the ORACLE's streams -> raw block byte-equal.  A third
 segment lengths and group sizes off their defaults, a third code a decode index and decode through it; the block goes
 through the device-resident calls, the host-pointer call or, unparsed, through the GPU's record finder; behind the
 host-pointer calls the oracle's streams are damaged (bit flips, truncation, random bytes) and decoded by both.
-    python tools/soak_roundtrip.py [cases, default 60] [first seed]"""
+    python tools/soak_roundtrip.py [cases, default 60] [first seed] [largest block in MiB, default 3]"""
 import os
 import sys
 import time
@@ -84,6 +84,7 @@ def several_blocks_in_flight(case, seed):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    max_bytes = (int(sys.argv[3]) if len(sys.argv) > 3 else 3) << 20
     t0 = time.time()
     done = damaged = 0
     for case in range(cases):
@@ -92,11 +93,11 @@ def main():
             continue
         rng = np.random.default_rng(seed0 + case)
         mode = int(rng.choice([2, 2, 3, 4, 4, 5]))
-        size = int(rng.integers(3000, 3 << 20))
+        size = int(rng.integers(3000, max_bytes))
         raw, _ = F.synth_fastq(size, mode, seed=seed0 + case)
         recs = F.parse_fastq(raw)
         how = int(rng.integers(0, 4))
-        if how and mode in (2, 4):
+        if how and mode in (2, 4) and len(recs) <= 20000:  # (a Python loop over the records: small blocks only)
             raw = rewrite_qualities(raw, recs, rng, how)
         # tables: own block, or those of a differently seeded block of another mode
         if rng.random() < 0.3:
@@ -175,7 +176,7 @@ def main():
             b.close()
         octx.close()
         ctx.close()
-        if case % 10 == 9:
+        if case % 10 == 9 or max_bytes > (8 << 20):
             print("case %d of %d, %d round trips, %.0f s" % (case + 1, cases, done, time.time() - t0), flush=True)
     print("soak: %d cases, %d encoded and decoded byte-exactly, the rest refused by both coders alike; %d damaged streams decoded with the oracle's verdict" % (cases, done, damaged))
 
