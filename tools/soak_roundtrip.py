@@ -87,7 +87,17 @@ def main():
     max_bytes = (int(sys.argv[3]) if len(sys.argv) > 3 else 3) << 20
     t0 = time.time()
     done = damaged = 0
+    verbose = bool(os.environ.get("SOAK_VERBOSE"))
+    if verbose:  # a case that does not come back: where it stands, after a minute
+        import faulthandler
+        faulthandler.enable()
     for case in range(cases):
+        if verbose:
+            print("case %d starts" % case, flush=True)
+            faulthandler.cancel_dump_traceback_later()
+            faulthandler.dump_traceback_later(60, exit=True)
+        if case % 10 == 0 and case:
+            print("case %d of %d, %d round trips, %.0f s" % (case, cases, done, time.time() - t0), flush=True)
         if case % 5 == 4:
             done += several_blocks_in_flight(case, seed0 + case) > 0
             continue
@@ -176,7 +186,7 @@ def main():
             b.close()
         octx.close()
         ctx.close()
-        if case % 10 == 9 or max_bytes > (8 << 20):
+        if max_bytes > (8 << 20):
             print("case %d of %d, %d round trips, %.0f s" % (case + 1, cases, done, time.time() - t0), flush=True)
     print("soak: %d cases, %d encoded and decoded byte-exactly, the rest refused by both coders alike; %d damaged streams decoded with the oracle's verdict" % (cases, done, damaged))
 
