@@ -4,20 +4,24 @@
 A step = one pass of the hot path over one batch: every block of the workload is ENCODED
 (seq + qual FSE streams, readlens, N side streams) from inputs already resident in HBM.
 
-N = 1   BASELINE.json configs[1]: 1 GiB of synthetic 150 bp reads (uniform ACGT, Phred ~ N(34,5)
-        clipped to [2,41]), reference default block size -R 256 (4 blocks of 256 MiB), frequency
-        tables from the first 128 MiB.
-N > 1   the same on every GPU (weak scaling: the work per GPU is fixed): rank r codes its own 1 GiB of
-        reads (4 blocks of 256 MiB, own seed) with ONE sample's tables, computed by rank 0 and broadcast
-        as bytes -- the units (blocks) are independent given the tables and are sharded over the ranks.
-        One process per GPU; no data-path collective and no RCCL call anywhere: the table broadcast, the
-        barriers and the max-over-ranks of the elapsed time go over gloo.  `--layout strong` is
-        BASELINE.json configs[2] instead: ONE 1 GiB job cut into 64 MiB blocks (16 of them), block b
-        coded by rank b mod N (total work fixed: two blocks per GPU at N = 8).
+`value`  BASELINE.json configs[1] on every GPU: rank r codes its own 1 GiB of synthetic 150 bp reads (uniform ACGT,
+         Phred ~ N(34,5) clipped to [2,41]; own seed) in the reference's default -R 256 blocks (4 blocks of 256 MiB)
+         with ONE sample's tables (first 128 MiB of rank 0's reads, broadcast as bytes).  The units (blocks) are
+         independent given the tables and are sharded over the ranks: work per GPU fixed, "scaling": "weak".
+`strong_config2_MBps`  (every N, after the timed region) BASELINE.json configs[2], the reference's scaling config:
+         ONE 1 GiB job cut into 64 MiB blocks (16 of them), block b coded by rank b mod N, tables from the job's
+         first 128 MiB: total work fixed (two blocks per GPU at N = 8).  At N = 1 the same number is also printed as
+         `encode_config3_MBps` (16 x 64 MiB on one GPU).  `--layout strong` makes THIS the timed `value` instead.
+`--gpus N` without a launcher (no WORLD_SIZE in the environment): the parent starts N fresh processes of this script
+         with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- before anything touches a GPU -- and
+         exits with their worst exit code; it refuses (exit 2) when fewer than N devices are visible.
+One process per GPU; no data-path collective and no RCCL call anywhere: the table broadcast, the barriers and the
+max-over-ranks of the elapsed time go over gloo.
 value = raw FASTQ bytes all ranks coded per second (max-over-ranks time).  After the timed region
 (not part of `value`): a whole timed block is byte-compared with the CPU oracle (also the source of
 `ratio_vs_reference`), decode of the same archive (configs[4]: blocks dealt over the N ranks), the
-CPU baselines, the host-pointer path incl. PCIe.  One JSON line on rank 0.
+CPU baselines, the host-pointer path incl. PCIe, other data (binned / constant / configs[3] / tiled REAL reads).
+One JSON line on rank 0.
 """
 import argparse
 import hashlib
@@ -34,7 +38,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 8 blocks in flight x (
 import numpy as np  # noqa: E402
 
 MB = 1e6
-PROFILE_TRAFFIC = "r03_traffic.json"  # counters and rocprof launch times of this round (tools/refresh_profiles.py)
+PROFILE_TRAFFIC = "r04_traffic.json"  # counters and rocprof launch times of this round (tools/refresh_profiles.py)
 
 
 def kernel_sources_sha():
@@ -46,6 +50,30 @@ def kernel_sources_sha():
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def profile_stamp():
+    """which committed counter profile bench.py would quote, and whether it was taken on this device code"""
+    out = {"file": "profiles/" + PROFILE_TRAFFIC, "current_kernel_sources_sha": kernel_sources_sha()}
+    try:
+        with open(os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)) as fh:
+            tj = json.load(fh)
+        out.update(commit=tj.get("commit"), kernel_sources_sha=tj.get("kernel_sources_sha"))
+    except Exception:
+        out.update(commit=None, kernel_sources_sha=None)
+    return out
+
+
+def load_profile(block_mib):
+    """profiles/<round>_traffic.json while it describes THIS device code and block size, else None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)) as fh:
+            tj = json.load(fh)
+    except Exception:
+        return None
+    if tj.get("kernel_sources_sha") != kernel_sources_sha() or block_mib != tj.get("block_mib", 256):
+        return None
+    return tj
 
 
 def make_workload(F, total_bytes, block_bytes, seed, first_id=0, mode=2):
@@ -83,11 +111,138 @@ def _oracle():
     return O
 
 
-def other_data(F, O, device, lanes, steps, kind, mode, total_mib, block_mib, sample_mib, decode_mib):
+REAL_FILES = ("SRR065390_sub_1.fastq", "SRR065390_sub_2.fastq", "without_ns.fastq")
+
+
+def make_real_workload(F, total_bytes, block_bytes, first_id=1):
+    """REAL statistics: the 2 851 reads of SRR065390 the reference ships as its test data (tests/golden = the
+    reference's test/data: 100 bp Illumina reads with N runs, '#' tails, poly-A) tiled to `total_bytes` with fresh
+    read ids -- every pass over the 2 851 reads in another order -- in blocks of about block_bytes.  The reference's
+    published numbers are on the full SRR065390 files (benchmark/Results.md:1-5), which cannot be fetched here.
+    Fixed-width records (header @SRR065390.<10 digits> <10 digits> length=100), built with numpy."""
+    seqs, quals = [], []
+    for f in REAL_FILES:
+        raw = np.fromfile(os.path.join(ROOT, "tests", "golden", f), dtype=np.uint8)
+        recs = F.parse_fastq(raw)
+        assert np.all(recs["len"] == 100)
+        idx = np.arange(100)
+        seqs.append(raw[recs["seq_off"][:, None].astype(np.int64) + idx])
+        quals.append(raw[recs["qual_off"][:, None].astype(np.int64) + idx])
+    seqs, quals = np.concatenate(seqs), np.concatenate(quals)
+    n_src = len(seqs)
+    head = np.frombuffer(b"@SRR065390.", dtype=np.uint8)
+    tail = np.frombuffer(b" length=100\n", dtype=np.uint8)
+    rec_bytes = head.size + 10 + 1 + 10 + tail.size + 100 + 3 + 100 + 1
+    per_block = max(1, block_bytes // rec_bytes)
+    blocks, done, next_id = [], 0, first_id
+    pow10 = 10 ** np.arange(9, -1, -1, dtype=np.int64)
+    while done < total_bytes:
+        n = min(per_block, (total_bytes - done) // rec_bytes)
+        if n == 0:
+            break
+        ids = next_id + np.arange(n, dtype=np.int64)
+        src = (ids * 1237 + 7 * (ids // n_src)) % n_src   # a permutation of the source reads per pass (1237 and 2851 are coprime)
+        digits = ((ids[:, None] // pow10) % 10 + 48).astype(np.uint8)
+        rec = np.empty((n, rec_bytes), dtype=np.uint8)
+        o = 0
+        for part in (head, digits, np.frombuffer(b" ", np.uint8), digits, tail, seqs[src], np.frombuffer(b"\n+\n", np.uint8), quals[src],
+                     np.frombuffer(b"\n", np.uint8)):
+            w = part.shape[-1]
+            rec[:, o:o + w] = part
+            o += w
+        assert o == rec_bytes
+        raw = rec.reshape(-1)
+        blocks.append((raw, F.parse_fastq(raw)))
+        next_id += n
+        done += n * rec_bytes
+    return blocks
+
+
+def child_environments(n, port, base=None):
+    """Environment of every rank the parent of `--gpus N` starts (one process per GPU, gloo rendezvous on
+    127.0.0.1): what `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1` would set."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        envs.append(e)
+    return envs
+
+
+def spawn_ranks(n, all_on_gpu0, argv):
+    """`--gpus N` from a bare shell: N fresh children of this script, started BEFORE this process has touched a GPU
+    (counting devices does not initialise one); never re-executes a process that has.  -> exit code."""
+    import socket
+    import subprocess
+    if not os.environ.get("FQ_BENCH_SPAWN_ONLY") and not all_on_gpu0:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but %d device(s) visible (use --all-on-gpu0 to rehearse the ranks on one GPU)\n" % (n, have))
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e) for e in child_environments(n, port)]
+    return max(abs(k.wait()) for k in kids)
+
+
+def strong_config2(F, farm, dist, rank, world, device, lanes, steps, mib, block_mib, sample_mib, oracle):
+    """BASELINE.json configs[2] (the reference's scaling config, src/process.cpp:46-68 with one worker per GPU): ONE job
+    of `mib` MiB in `block_mib` MiB blocks, block b -> rank b mod world, tables from the job's first `sample_mib` MiB
+    (rank 0, broadcast).  Barrier, `steps` passes over this rank's blocks, barrier; max over ranks."""
+    import torch
+    job = make_workload(F, mib << 20, block_mib << 20, seed=28)   # the same job on every rank (deterministic per read)
+    sft = qft = None
+    if rank == 0:
+        sft, qft = sample_tables(F, job, sample_mib << 20, device)
+    sft, qft = farm.broadcast_tables(sft, qft, dist)
+    mine = farm.shard_blocks(len(job), rank, world)
+    ctx = F.Context(sft, qft, device=device)
+    ctx.set_lanes(lanes)
+    db = [ctx.dblock(*job[b]) for b in mine]
+    for b in db:
+        b.encode()
+    ctx.sync()
+    farm.barrier(dist)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for b in db:
+            b.encode()
+    ctx.sync()
+    farm.barrier(dist)
+    dt = farm.reduce_max(time.perf_counter() - t0, dist)
+    ok = all(b.status()[0] == 0 for b in db)
+    job_bytes = sum(r.size for r, _ in job)
+    out = {"config": "BASELINE configs[2]: ONE job of %d MiB in %d MiB blocks, block b -> rank b mod %d, tables from the first %d MiB"
+                     % (mib, block_mib, world, sample_mib),
+           "MBps": round(job_bytes * steps / dt / MB, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "job_blocks": len(job), "blocks_this_gpu": len(mine), "scaling": "strong",
+           "all_rc_zero": bool(farm.reduce_sum(0.0 if ok else 1.0, dist) == 0.0)}
+    if oracle is not None and rank == 0 and db:
+        octx = oracle.OracleCtx(sft, qft)
+        e = octx.encode(*job[mine[-1]])
+        g = db[-1].fetch()
+        out["oracle_block_all_equal"] = bool(e["rc"] == 0 and all(np.array_equal(g[k], e[k]) for k in ("seq", "qual", "readlens", "n_count", "n_pos")))
+        octx.close()
+    for b in db:
+        b.close()
+    ctx.close()
+    return out
+
+
+def other_data(F, O, device, lanes, steps, kind, mode, total_mib, block_mib, sample_mib, decode_mib, blocks=None, classes=False):
     """The same measurement on data that is NOT the headline config (after the timed region, rank 0):
     encode MB/s of `total_mib` in `block_mib` blocks with `lanes` blocks in flight, one WHOLE block
-    byte-compared with the oracle, and the decode walk's ns per symbol on 4 x `decode_mib` MiB of it."""
-    blocks = make_workload(F, total_mib << 20, block_mib << 20, seed=28, mode=mode)
+    byte-compared with the oracle, and the decode walk's ns per symbol on 4 x `decode_mib` MiB of it.
+    blocks: a prebuilt workload instead of synth mode `mode`; classes: the quality segments of one block by class."""
+    make_small = None
+    if blocks is None:
+        blocks = make_workload(F, total_mib << 20, block_mib << 20, seed=28, mode=mode)
+    else:
+        make_small = lambda: make_real_workload(F, 4 * decode_mib << 20, decode_mib << 20, first_id=500_000_000)  # noqa: E731
     sft, qft = sample_tables(F, blocks, sample_mib << 20, device)
     ctx = F.Context(sft, qft, device=device)
     ctx.set_lanes(lanes)
@@ -105,6 +260,9 @@ def other_data(F, O, device, lanes, steps, kind, mode, total_mib, block_mib, sam
     out = {"data": kind, "blocks": "%d x %d MiB" % (len(blocks), block_mib), "steps": steps,
            "MBps": round(raw_bytes * steps / dt / MB, 1), "ms_per_step": round(dt / steps * 1e3, 3)}
     sizes = [b.status() for b in db]
+    if classes:  # (the last block is the last one its lane coded: the lane's segment table is still this block's)
+        out["quality_segments_by_class"] = db[-1].qual_segment_classes()
+        out["quality_segment_symbols"] = "segments of one block's quality chains (4096 symbols each, one chain per context)"
     out["rc"] = [rc for rc, _ in sizes]
     out["seq_bytes"] = int(sum(st["seq_len"] for _, st in sizes))
     out["qual_bytes"] = int(sum(st["qual_len"] for _, st in sizes))
@@ -118,7 +276,7 @@ def other_data(F, O, device, lanes, steps, kind, mode, total_mib, block_mib, sam
     for b in db:
         b.close()
     if decode_mib:  # the serial walk per (block, stream): 4 blocks = 8 chains side by side
-        small = make_workload(F, 4 * decode_mib << 20, decode_mib << 20, seed=29, mode=mode)
+        small = make_small() if make_small else make_workload(F, 4 * decode_mib << 20, decode_mib << 20, seed=29, mode=mode)
         sdb = [ctx.dblock(raw, recs) for raw, recs in small]
         for b in sdb:
             b.encode()
@@ -204,10 +362,20 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-host", action="store_true")
     ap.add_argument("--skip-other-data", action="store_true", help="no binned / constant / configs[3] runs after the timed region")
+    ap.add_argument("--skip-strong", action="store_true", help="no configs[2] run (ONE job in 64 MiB blocks dealt over the ranks) after the timed region")
     args = ap.parse_args()
+
+    # `--gpus N` without a launcher: N fresh processes of this script, before anything here touches a GPU
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, args.all_on_gpu0, sys.argv[1:]))
+    if os.environ.get("FQ_BENCH_SPAWN_ONLY"):  # CPU test of the launcher: what a rank was started with
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        return
 
     from fqcomp28_amd import farm
     rank, world, local = farm.dist_env()
+    if world != max(args.gpus, 1) and rank == 0:
+        sys.stderr.write("bench.py: note: --gpus %d but the launcher started %d rank(s); the launcher's count is used\n" % (args.gpus, world))
     dist = farm.init_dist()  # gloo; before anything touches the GPU
     import torch
     if args.all_on_gpu0:
@@ -271,7 +439,20 @@ def main():
     step()
     ctx.sync()
     kern_all, _ = spans_of()
-    dom_name = max(kern_all.items(), key=lambda kv: kv[1])[0] if kern_all else None
+    # The roofline kernel is the one the PROFILE names: largest total rocprofv3 duration in the committed kernel-trace
+    # summary of this device code (profiles/<round>_traffic.json, bound by the hash over the device sources).  The
+    # HIP-event table of this one untimed step only decides without such a profile: with four blocks in flight its
+    # spans move by +-30 % from run to run.
+    profile = load_profile(block_mib)
+    dom_from = "largest total rocprofv3 duration in profiles/%s (same device code)" % PROFILE_TRAFFIC
+    dom_name = None
+    if profile:
+        ranked = sorted(((k, v.get("rocprof_total_ms", 0.0)) for k, v in profile["kernels"].items() if k in kern_all), key=lambda kv: -kv[1])
+        if ranked and ranked[0][1] > 0:
+            dom_name = ranked[0][0]
+    if dom_name is None:
+        dom_name = max(kern_all.items(), key=lambda kv: kv[1])[0] if kern_all else None
+        dom_from = "HIP-event spans of one untimed step (no committed profile of this device code)"
     ctx.enable_timing(True, only=None if os.environ.get("FQ_BENCH_ALL_EVENTS") else dom_name)
     barrier()
     t0 = time.perf_counter()
@@ -335,20 +516,14 @@ def main():
     # HBM bytes of that kernel: bench.py cannot collect counters itself (separate rocprofv3 --pmc
     # passes of this script, tools/refresh_profiles.py).  The committed figure is quoted only while
     # the device code is the code it was measured on; otherwise null.
-    traffic, traffic_src, rocprof_avg_ms = None, None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)) as fh:
-            tj = json.load(fh)
-        traffic_src = {"file": "profiles/" + PROFILE_TRAFFIC, "commit": tj.get("commit"), "kernel_sources_sha": tj.get("kernel_sources_sha"),
-                       "current_kernel_sources_sha": kernel_sources_sha()}
-        if tj.get("kernel_sources_sha") == traffic_src["current_kernel_sources_sha"] and block_mib == tj.get("block_mib", 256):
-            k = tj.get("kernels", {}).get(dom[0])
-            if k:
-                traffic = k.get("traffic_bytes_per_launch")
-                rocprof_avg_ms = k.get("rocprof_avg_launch_ms")
-            traffic_src["block_traffic_bytes"] = tj.get("block_traffic_bytes")
-    except Exception:
-        pass
+    traffic, rocprof_avg_ms = None, None
+    traffic_src = profile_stamp()
+    if profile:
+        k = profile["kernels"].get(dom[0])
+        if k:
+            traffic = k.get("traffic_bytes_per_launch")
+            rocprof_avg_ms = k.get("rocprof_avg_launch_ms")
+        traffic_src["block_traffic_bytes"] = profile.get("block_traffic_bytes")
     # One figure per key: `achieved` / `frac` divide by the kernel's own duration -- the rocprofv3 launch
     # time of the committed profile while the device code is the code it was taken on, else (null
     # profile) the HIP-event span measured here; the span (which also holds the wait for room on a chip
@@ -356,7 +531,9 @@ def main():
     span_achieved = achieved
     if rocprof_avg_ms:
         achieved = alg_dom / (rocprof_avg_ms / 1e3) / 1e9
-    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": dom[0], "kernel_chosen_by": dom_from,
+                "rocprof_kernel": (profile["kernels"].get(dom[0], {}).get("rocprof_kernel") if profile else None),
+                "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "frac_from": "rocprofv3 launch time of the committed profile (same device code)" if rocprof_avg_ms
                 else "HIP-event span of this run (no committed profile of this device code)",
                 "frac_event_span": round(span_achieved / 8000.0, 5), "achieved_event_span": round(span_achieved, 2),
@@ -369,9 +546,18 @@ def main():
                 "kernels_ms_from": "one untimed step after the warm-up (events around every kernel group); the roofline kernel: the timed steps",
                 "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
 
+    extra = {}
+    # ---- BASELINE configs[2] at every N (after the timed region; all ranks): the reference's own scaling config
+    if not args.skip_strong and layout != "strong":
+        sc2 = strong_config2(F, farm, dist, rank, world, device, max(1, min(args.lanes, 8)), max(3, args.steps), 1024, 64, args.sample_mib,
+                             None if args.skip_cpu else _oracle())
+        extra["strong_config2_MBps"] = sc2["MBps"]
+        extra["strong_config2"] = sc2
+        if world == 1:
+            extra["encode_config3_MBps"] = sc2["MBps"]   # 16 x 64 MiB on one GPU: the same run under the name the blocks' size gives it
+
     # ---- decode (after the timed region): the same archive, blocks dealt over the ranks exactly as
     # they were coded (configs[4]); then extensions: decode index, many small blocks
-    extra = {}
     if not args.skip_decode:
         for b in dblocks:
             b.wipe()
@@ -548,7 +734,13 @@ def main():
         od = [other_data(F, Oc, device, lanes, 5, "binned qualities: four levels at 5/10/15/70 %, kept w.p. 0.85 (synth mode 3)", 3, 1024, 256, 128, 16),
               other_data(F, Oc, device, lanes, 5, "constant: every base A, every quality F (synth mode 5)", 5, 1024, 256, 128, 16),
               other_data(F, Oc, device, lanes, 5, "BASELINE configs[3]: 256 MiB, length U[50,300], 1 % N (synth mode 4), in -R 64 blocks", 4, 256, 64, 128, 0)]
-        extra["encode_binned_MBps"], extra["encode_constant_MBps"], extra["encode_config4_MBps"] = (o["MBps"] for o in od)
+        real_blocks = make_real_workload(F, 1024 << 20, 256 << 20)
+        od.append(other_data(F, Oc, device, lanes, 5, "REAL reads: the reference's 2 851 test reads of SRR065390 (100 bp, N runs, '#' tails) tiled to 4 x 256 MiB "
+                             "with fresh read ids, tables from the first 128 MiB", None, 1024, 256, 128, 16, blocks=real_blocks, classes=True))
+        del real_blocks
+        extra["encode_real_MBps"] = od[3]["MBps"]
+        extra["decode_real_ns_per_symbol"] = od[3].get("decode_ns_per_symbol_per_lane")
+        extra["encode_binned_MBps"], extra["encode_constant_MBps"], extra["encode_config4_MBps"] = (o["MBps"] for o in od[:3])
         extra["decode_binned_ns_per_symbol"] = od[0].get("decode_ns_per_symbol_per_lane")
         extra["decode_constant_ns_per_symbol"] = od[1].get("decode_ns_per_symbol_per_lane")
         extra["other_data"] = od

@@ -94,6 +94,7 @@ _PROTOS = {
     "fqgpu_dblock_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fqgpu_dblock_longest_chain": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "fqgpu_dblock_qual_segment_classes": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
     "fqgpu_ctx_set_index_stride": (C.c_int, [C.c_void_p, C.c_uint]),
     "fqgpu_dblock_index_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "fqgpu_dblock_fetch_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
@@ -288,6 +289,12 @@ class DBlock:
         a, b = C.c_uint(), C.c_uint()
         _check(lib().fqgpu_dblock_longest_chain(self.h, C.byref(a), C.byref(b)), "dblock_longest_chain")
         return a.value, b.value
+
+    def qual_segment_classes(self):
+        """segments of the quality chains of the last encode by class -> dict(transparent, anchored, uniform, opaque)"""
+        c = (C.c_size_t * 4)()
+        _check(lib().fqgpu_dblock_qual_segment_classes(self.ctx.h, self.h, c), "dblock_qual_segment_classes")
+        return dict(transparent=c[0], anchored=c[1], uniform=c[2], opaque=c[3])
 
     def fetch(self, raw=False):
         rc, st = self.status()

@@ -500,6 +500,7 @@ extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
   free_tables(ctx->tab[1]);
   DevBuf *bufs[] = {&ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc, &ctx->dec_chunks, &ctx->dec_recstart};
   for (DevBuf *b : bufs) b->release();
+  ctx->hp_parse.release();  // the device parser's scratch (fqgpu_ctx_reserve / fqgpu_encode_begin without a record table)
   for (int i = 0; i < FQ_MAX_LANES; i++) free_lane(ctx->lanes[i]);
   if (ctx->hp_block) fqgpu_dblock_destroy(ctx->hp_block);
   if (ctx->hp_ev_h2d) (void)hipEventDestroy(ctx->hp_ev_h2d);
@@ -806,6 +807,24 @@ extern "C" int fqgpu_dblock_longest_chain(const fqgpu_dblock *b, unsigned *seq_s
   if (seq_segments) *seq_segments = tmp.s[0].refixed;
   if (qual_segments) *qual_segments = tmp.s[1].refixed;
   return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_qual_segment_classes(fqgpu_ctx *ctx, const fqgpu_dblock *b, size_t counts[4]) {
+  if (!ctx || !b || !counts) return FQGPU_E_ARG;
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  int rc = fqgpu_sync(ctx);
+  if (rc) return rc;
+  if (!b->diag_cls || !b->diag_n_segs) return FQGPU_E_ARG;  // no encode of this block yet
+  uint32_t n = 0;
+  FQ_HIP(hipMemcpy(&n, b->diag_n_segs, 4, hipMemcpyDeviceToHost));
+  if (!n) return FQGPU_OK;
+  uint8_t *cls = static_cast<uint8_t *>(malloc(n));
+  if (!cls) return FQGPU_E_NOMEM;
+  const hipError_t he = hipMemcpy(cls, b->diag_cls, n, hipMemcpyDeviceToHost);
+  if (he == hipSuccess)
+    for (uint32_t i = 0; i < n; i++) counts[cls[i] == 1 ? 0 : cls[i] == 0xFF ? 2 : cls[i] == 0 ? 3 : 1]++;
+  free(cls);
+  return he == hipSuccess ? FQGPU_OK : fq_hip_error(he, __FILE__, __LINE__);
 }
 
 extern "C" int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t *seq_out, uint8_t *qual_out,

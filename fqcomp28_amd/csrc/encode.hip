@@ -307,6 +307,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     sa.entry_state = reinterpret_cast<uint16_t *>(sab + sa_entry);
     sa.cand_exit = reinterpret_cast<uint16_t *>(sab + sa_cand);
     sa.cls = sab + sa_cls;
+    if (M::STREAM == 1) { b->diag_cls = sa.cls; b->diag_n_segs = arrays + B + (B + 1) + B; }  // seg_base[B]
     uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
     const unsigned cand_grid = min(gen_max_segs / (64 / SEG_SLOT) + 1, 32u * ctx->n_cus);
     if (!dbg_off) hipLaunchKernelGGL(k_seg_scan<M>, dim3((gen_max_segs + 3) / 4), dim3(256), 0, st, sc.sorted_sym.as<uint8_t>(),

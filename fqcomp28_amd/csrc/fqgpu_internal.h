@@ -107,6 +107,7 @@ struct KernelTimer;  // api.cpp
 struct ParseScratch {
   DevBuf cnt, base, sum, nl_pos, scan_tmp;
   size_t total_nl = 0;  // newlines counted by fq_parse_count
+  void release() { for (DevBuf *b : {&cnt, &base, &sum, &nl_pos, &scan_tmp}) b->release(); total_nl = 0; }
 };
 
 // Scratch of the encode pipeline for one stream.
@@ -204,6 +205,10 @@ struct fqgpu_dblock {
   // decode index (extension): device copy per stream, valid bytes, allocated bytes
   uint8_t *index[2] = {nullptr, nullptr};
   size_t index_bytes[2] = {0, 0}, index_cap[2] = {0, 0};
+  // diagnostics (fqgpu_dblock_qual_segment_classes): where the lane that coded this block last left the classes of its
+  // quality segments -- lane scratch, valid until that lane codes another block
+  const uint8_t *diag_cls = nullptr;
+  const uint32_t *diag_n_segs = nullptr;
 };
 
 // Decode index of one stream: header, then one snapshot per multiple of `stride` symbols.

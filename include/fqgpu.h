@@ -204,6 +204,13 @@ int fqgpu_dblock_status(const fqgpu_dblock *b, size_t *seq_len, size_t *qual_len
 /* diagnostics of the last encode (after fqgpu_sync): the longest run of symbols one lane
  * had to walk serially, per stream (the latency floor of the chain kernels) */
 int fqgpu_dblock_longest_chain(const fqgpu_dblock *b, unsigned *seq_steps, unsigned *qual_steps);
+/* diagnostics of the last encode of this block: how many segments of the quality chains
+ * (src/fse_quality.cpp:19-52 cut into segments of S symbols) the chain kernels took as
+ * counts[0] transparent (a symbol with one table cell inside: the state behind it is known),
+ * [1] anchored (a symbol with <= 64 cells: one walk per candidate), [2] uniform (S times one symbol:
+ * a power of one transition), [3] opaque (the full entry-state -> exit-state function).  Reads the
+ * scratch of the encode lane that coded the block: valid until that lane codes another block. */
+int fqgpu_dblock_qual_segment_classes(fqgpu_ctx *ctx, const fqgpu_dblock *b, size_t counts[4]);
 /* copies results to the host (synchronous); any pointer may be NULL */
 int fqgpu_dblock_fetch(fqgpu_ctx *ctx, const fqgpu_dblock *b, uint8_t *seq_out, uint8_t *qual_out,
                        uint16_t *readlens_out, uint16_t *n_count_out, uint16_t *n_pos_out,

@@ -826,13 +826,52 @@ def test_one_256mib_block_bench_layout_matches_oracle(F):
 
 
 @pytest.mark.timeout(1200)
-def test_single_1gib_block_at_the_edge_of_the_capacity_rule(F):
-    """configs[1] read literally ("single block stream", -R 1024): 480 M symbols per stream, the
-    sequence stream within a few hundred bytes of its capacity n/4 + 1024."""
+def test_single_768mib_block_360M_symbols_under_the_plain_capacity_rule(F):
+    """The largest single block of config-2 reads that still FITS the reference's capacity rule with tables from
+    its first 128 MiB (src/workspace.h:21-35: the sequence stream ends 47 bytes below n/4 + 1024): 360 M symbols per
+    stream -- three times the bench's block -- all five streams byte for byte, then the round trip."""
+    rc, st = _big_block_vs_oracle(F, 768)
+    assert rc == 0 and st["n_bases"] > 360_000_000
+    assert F.bound_seq(st["n_bases"]) - st["seq_len"] < 1024
+
+
+@pytest.mark.timeout(1200)
+def test_single_1gib_block_is_refused_under_the_plain_capacity_rule_by_both_coders(F):
+    """configs[1] read literally ("single block stream", -R 1024) with tables from the first 128 MiB: the sequence
+    stream needs 239 bytes more than n/4 + 1024, the reference's endChunk returns 0
+    (src/fse_common.hpp:85-90) -- the oracle and the GPU coder both say FQGPU_E_OVERFLOW.  Nothing is compared here
+    but the verdict; the bytes of a block of this size are compared in the next test."""
     rc, st = _big_block_vs_oracle(F, 1024)
-    assert rc in (0, -1) and st["n_bases"] > 479_000_000
-    if rc == 0:
-        assert F.bound_seq(st["n_bases"]) - st["seq_len"] < 1024
+    assert rc == -1 and st["n_bases"] > 479_000_000
+
+
+@pytest.mark.timeout(1200)
+def test_single_block_of_480M_symbols_with_room_matches_oracle_byte_for_byte(F):
+    """The same 1 GiB block (480 M symbols per stream: u32 encode indices up to 4.8e8, 14 659 tiles, 117 K segments
+    per stream, three-level resolves) with 64 KiB of room handed to BOTH coders (fqgpu_encode_block judges the
+    overflow rule against the caller's capacity, like the oracle): rc == 0, every stream byte for byte; then the
+    GPU decodes the ORACLE's streams back to the block."""
+    raw, _ = F.synth_fastq(1024 << 20, 2, seed=28)
+    recs = F.parse_fastq(raw)
+    srecs = recs[recs["qual_off"] + recs["len"] < (128 << 20)]
+    sft, qft = F.freq_tables(raw, srecs)
+    n_bases = int(recs["len"].sum())
+    assert n_bases > 480_000_000
+    seq_cap = F.bound_seq(n_bases) + (64 << 10)
+    octx = O.OracleCtx(sft, qft)
+    e = octx.encode(raw, recs, seq_cap=seq_cap)
+    octx.close()
+    assert e["rc"] == 0 and e["seq"].size > F.bound_seq(n_bases)   # it does NOT fit the plain rule
+    ctx = F.Context(sft, qft)
+    ctx.set_lanes(1)
+    g = ctx.encode_block(raw, recs, seq_cap=seq_cap)
+    assert g["rc"] == 0
+    for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
+        assert np.array_equal(g[k], e[k]), k
+    del g
+    rc, out = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, O.blank_skeleton(raw, recs))
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
 
 
 # ---------------------------------------------------------------- extension: decode index
@@ -954,6 +993,35 @@ def test_page_locked_blocks_are_cached_on_free(F):
     assert small
     L.fqgpu_host_free(small)
     assert L.fqgpu_host_trim() == 0   # not pinned, not cached
+
+
+def test_handles_created_and_destroyed_in_a_loop_give_all_device_memory_back(F):
+    """Advisor finding of round 3: the device parser's scratch (fqgpu_ctx::hp_parse, grown by fqgpu_ctx_reserve and
+    by every fqgpu_encode_begin without a record table -- the farm's default path) was never released.  Handles that
+    code an unparsed chunk are created and destroyed in a loop; the free device memory must not drift."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+    raw, recs = _synth(F, 2, 24 << 20)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    def cycle():
+        ctx = F.Context(sft, qft)
+        ctx.set_lanes(1)
+        g = ctx.encode_raw(raw)   # fqgpu_encode_begin(recs = NULL): table built on the device
+        assert g["rc"] == 0 and len(g["recs"]) == len(recs)
+        ctx.close()
+    cycle()   # first use: the runtime's own pools, code objects, the pinned cache
+    F.lib().fqgpu_host_trim()
+    before = free_bytes()
+    for _ in range(6):
+        cycle()
+    F.lib().fqgpu_host_trim()
+    after = free_bytes()
+    # the parser's scratch for a 24 MiB chunk is ~1.5 MB per handle: six leaked ones would be ~9 MB
+    assert before - after < (2 << 20), (before, after)
 
 
 # ---------------------------------------------------------------- the C++ drop-in shim

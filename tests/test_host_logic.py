@@ -160,3 +160,74 @@ def test_block_farm_two_ranks_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert "[0, 2, 4, 6, 8]" in outs[0] and "[1, 3, 5, 7]" in outs[1]
+
+
+# ---------------------------------------------------------------- bench.py: launcher, workloads, profile binding (no GPU)
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_bench_gpus_n_from_a_bare_shell_starts_n_ranks():
+    """`python bench.py --gpus 3` without a launcher: the parent starts three fresh processes with the environment
+    torch.distributed.run would give them (gloo rendezvous on 127.0.0.1) and never touches a GPU itself; with fewer
+    devices visible than ranks asked for it refuses with a non-zero exit instead of coding on one GPU."""
+    import json
+    env = dict(os.environ, FQ_BENCH_SPAWN_ONLY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--all-on-gpu0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ranks = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")), key=lambda d: int(d["RANK"]))
+    assert [d["RANK"] for d in ranks] == ["0", "1", "2"] and [d["LOCAL_RANK"] for d in ranks] == ["0", "1", "2"]
+    assert all(d["WORLD_SIZE"] == "3" and d["MASTER_ADDR"] == "127.0.0.1" for d in ranks)
+    assert len({d["MASTER_PORT"] for d in ranks}) == 1 and 1024 < int(ranks[0]["MASTER_PORT"]) < 65536
+    envs = _bench().child_environments(2, 29501, base={"PATH": "/bin"})
+    assert [(e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_PORT"]) for e in envs] == [("0", "0", "2", "29501"), ("1", "1", "2", "29501")]
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/bin" for e in envs)
+    # no GPU in this container: two ranks on real devices are refused, loudly
+    env.pop("FQ_BENCH_SPAWN_ONLY")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "device(s) visible" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_real_read_workload_is_wellformed_and_tiles_the_reference_reads(F, golden_dir):
+    """bench.py's REAL-statistics workload: the reference's 2 851 test reads tiled with fresh ids -- whole records, every
+    read one of the source reads, every pass a permutation of all of them, blocks the oracle codes under the capacity rule."""
+    bench = _bench()
+    blocks = bench.make_real_workload(F, 3 << 20, 1 << 20)
+    assert len(blocks) == 3
+    src = set()
+    for f in bench.REAL_FILES:
+        raw, recs = O.load_fastq(os.path.join(golden_dir, f))
+        for r in recs:
+            src.add((raw[r["seq_off"]: r["seq_off"] + 100].tobytes(), raw[r["qual_off"]: r["qual_off"] + 100].tobytes()))
+    seen, ids = [], []
+    for raw, recs in blocks:
+        assert np.array_equal(O.parse_fastq(raw), recs) and abs(raw.size - (1 << 20)) < 300
+        for r in recs:
+            seen.append((raw[r["seq_off"]: r["seq_off"] + 100].tobytes(), raw[r["qual_off"]: r["qual_off"] + 100].tobytes()))
+        ids += [int(bytes(raw[o - 44 + 11: o - 44 + 21])) for o in recs["seq_off"]]
+    assert ids == list(range(1, len(ids) + 1)) and set(seen) <= src
+    p1, p2 = seen[2851 - 1: 2 * 2851 - 1], seen[2 * 2851 - 1: 3 * 2851 - 1]   # read ids 2851 .. 5701 and 5702 .. 8552: two whole passes
+    assert len(seen) > 3 * 2851 and len(set(p1)) == len(src) == len(set(p2)) and p1 != p2
+    _, _, sft, qft = O.freq_tables(*blocks[0])
+    e = O.OracleCtx(sft, qft).encode(*blocks[1])
+    assert e["rc"] == 0 and e["n_pos"].size > 1000   # the N runs of the real reads are there
+
+
+def test_bench_quotes_a_profile_only_for_the_device_code_it_was_taken_on(tmp_path, monkeypatch):
+    bench = _bench()
+    import json
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "fqcomp28_amd" / "csrc")
+    (tmp_path / "fqcomp28_amd" / "csrc" / "a.hip").write_text("kernel v1")
+    sha = bench.kernel_sources_sha()
+    prof = {"commit": "x", "kernel_sources_sha": sha, "block_mib": 256, "kernels": {"seq.setfunc": {"rocprof_total_ms": 40.0}, "qual.scatter": {"rocprof_total_ms": 30.0}}}
+    (tmp_path / "profiles" / bench.PROFILE_TRAFFIC).write_text(json.dumps(prof))
+    assert bench.load_profile(256)["kernels"]["seq.setfunc"]["rocprof_total_ms"] == 40.0
+    assert bench.load_profile(64) is None                       # another block size: not this profile's kernels
+    (tmp_path / "fqcomp28_amd" / "csrc" / "a.hip").write_text("kernel v2")
+    assert bench.load_profile(256) is None and bench.profile_stamp()["kernel_sources_sha"] == sha != bench.profile_stamp()["current_kernel_sources_sha"]

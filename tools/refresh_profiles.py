@@ -1,4 +1,4 @@
-"""Copies the rocprofv3 summaries of tools/profile_round.sh <tag> (gpurun_out/<tag>_*) and the default bench
+"""Runs HERE after the call: copies the rocprofv3 summaries of tools/profile_round.sh <tag> (gpurun_out/<tag>_*) and the default bench
 line (gpurun_out/<tag>_bench_default.log) into profiles/ and prints the figures DESIGN.md quotes.
     python tools/refresh_profiles.py [tag, default r03]
 Everything is stamped with the commit it was measured on and with the hash of the device code
@@ -17,7 +17,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
 sys.path.insert(0, R)
 import bench  # noqa: E402  (kernel_sources_sha)
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def newest(pat):
@@ -48,57 +48,19 @@ commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=R, captu
 sha = bench.kernel_sources_sha()
 f4 = newest(R + "gpurun_out/%s_" % TAG + "prof4/**/*kernel_stats.csv")
 f1 = newest(R + "gpurun_out/%s_" % TAG + "prof1/**/*kernel_stats.csv")
-s4, s1 = list(csv.DictReader(open(f4))), list(csv.DictReader(open(f1)))
 shutil.copy(f4, R + "profiles/%s_bench_encode_kernel_stats.csv" % TAG)
 shutil.copy(f1, R + "profiles/%s_encode_one_lane_kernel_stats.csv" % TAG)
-one = {short(r["Name"]): float(r["AverageNs"]) / 1e6 for r in s1}
-four = {short(r["Name"]): float(r["AverageNs"]) / 1e6 for r in s4}
+# the traffic file the box wrote BEFORE its default bench run (tools/make_traffic_json.py): the one the default line quotes
+shutil.copy(R + "gpurun_out/%s_traffic.json" % TAG, R + "profiles/%s_traffic.json" % TAG)
+shutil.copy(R + "gpurun_out/%s_pmc_hbm_traffic_per_launch.csv" % TAG, R + "profiles/%s_pmc_hbm_traffic_per_launch.csv" % TAG)
+tj = json.load(open(R + "profiles/%s_traffic.json" % TAG))
+assert tj["kernel_sources_sha"] == sha, "the profiles were taken on other device code than this checkout's"
+s4 = list(csv.DictReader(open(f4)))
+one = {short(r["Name"]): float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(f1))}
 for r in s4[:28]:
     n = short(r["Name"])
     print("%-40s calls %4s avg %7.3f ms  (1 lane %7.3f)  %5s%%" % (n[:40], r["Calls"], float(r["AverageNs"]) / 1e6, one.get(n, float("nan")), r["Percentage"][:5]))
-
-
-def agg(path):
-    a = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
-        n = short(r["Kernel_Name"])
-        a[n][0] += 1
-        a[n][1] += float(r["Counter_Value"])
-    return a
-
-
-fa = agg(newest(R + "gpurun_out/%s_" % TAG + "pmc_f/**/*counter_collection.csv"))
-wa = agg(newest(R + "gpurun_out/%s_" % TAG + "pmc_w/**/*counter_collection.csv"))
 skip = ("k_hist_", "k_build", "k_normalize", "k_fill", "k_log", "k_reset", "k_probe")
-out = []
-for n in sorted(fa, key=lambda k: -(fa[k][1] * 2 + wa.get(k, [0, 0])[1])):
-    c = fa[n][0]
-    fk = fa[n][1] / c
-    wk = wa.get(n, [1, 0])[1] / max(wa.get(n, [1, 0])[0], 1)
-    out.append((n, c, fk, wk, (2 * fk + wk) * 1024 / 1e6))
-with open(R + "profiles/%s_pmc_hbm_traffic_per_launch.csv" % TAG, "w") as f:
-    f.write("kernel,launches,FETCH_SIZE_KB_per_launch_raw,WRITE_SIZE_KB_per_launch,HBM_MB_per_launch_fetch_doubled\n")
-    for o in out:
-        f.write("\"%s\",%d,%.1f,%.1f,%.1f\n" % o)
-# the PMC passes run 1 warm-up + 1 table + 1 timed step of 4 blocks = 12 block encodes (memsets are not kernels of ours)
-n_block_encodes = max(o[1] for o in out if o[0].startswith("k_tile_partition<QualModel>"))
-block_mb = sum(o[4] * o[1] for o in out if not o[0].startswith(skip)) / n_block_encodes
-print("HBM MB per 256 MiB block (all encode kernels, FETCH doubled):", round(block_mb, 1), "over", n_block_encodes, "block encodes")
-for o in out[:14]:
-    print("%-40s x%3d  %8.1f MB per launch (fetch raw %7.1f MB, write %7.1f MB)" % (o[0][:40], o[1], o[4], o[2] * 1.024 / 1e3, o[3] * 1.024 / 1e3))
-per = {o[0]: o for o in out}
-kernels = {}
-for span, names in SPAN_KERNELS.items():
-    if all(n in per for n in names):
-        kernels[span] = {"rocprof_kernel": ", ".join(names),
-                         "traffic_bytes_per_launch": int(sum((2 * per[n][2] + per[n][3]) * 1024 for n in names)),
-                         "rocprof_avg_launch_ms": round(sum(four.get(n, 0.0) for n in names), 4),
-                         "rocprof_avg_launch_ms_one_lane": round(sum(one.get(n, 0.0) for n in names), 4)}
-json.dump({"commit": commit, "kernel_sources_sha": sha, "block_mib": 256, "block_traffic_bytes": int(block_mb * 1e6), "kernels": kernels,
-           "note": "separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --steps 1 --warmup 1 --skip-cpu --skip-decode --skip-host "
-                   "(256 MiB blocks); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); "
-                   "average launch times from the --kernel-trace --stats passes of the same commit"},
-          open(R + "profiles/%s_traffic.json" % TAG, "w"), indent=1)
 
 sq = sorted(glob.glob(R + "gpurun_out/%s_" % TAG + "pmc_sq/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
 if sq:
@@ -143,5 +105,13 @@ json.dump(e, open(R + "profiles/%s_bench_encode_line.json" % TAG, "w"), indent=1
 box_sha = e.get("kernel_sources_sha")
 print("commit", commit, "kernel sources sha", sha, "(profiled box saw %s)" % box_sha)
 assert box_sha in (None, sha), "the profiles were taken on other device code than this checkout's"
+# the default line must quote THIS round's file, number for number, and name the kernel the kernel-trace summary names
+rk = d["roofline"]["kernel"]
+assert d["roofline"]["traffic_from_committed_profile"]["kernel_sources_sha"] == sha
+assert d["roofline"]["rocprof_avg_launch_ms"] == tj["kernels"][rk]["rocprof_avg_launch_ms"], (d["roofline"]["rocprof_avg_launch_ms"], tj["kernels"][rk])
+assert d["roofline"]["traffic"] == tj["kernels"][rk]["traffic_bytes_per_launch"]
+assert d["roofline"]["traffic_from_committed_profile"]["block_traffic_bytes"] == tj["block_traffic_bytes"]
+assert tj["kernels"][rk]["rocprof_kernel"].split(",")[0] in short(s4[0]["Name"]) or short(s4[0]["Name"]).startswith("__amd"), (rk, s4[0]["Name"])
+print("roofline kernel", rk, "= first row of the kernel-trace summary:", short(s4[0]["Name"]))
 print("default:", d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"].get("rocprof_avg_launch_ms"), d["cpu_baseline"]["value"],
       d["gpu_over_cpu_all_cores"], "rocprof run:", e["value"])
