@@ -75,6 +75,7 @@ _PROTOS = {
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fqgpu_encode_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "fqgpu_encode_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "fqgpu_encode_cancel": (C.c_int, [C.c_void_p]),
     "fqgpu_encode_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                    C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -1070,6 +1070,14 @@ extern "C" int fqgpu_encode_wait(fqgpu_ctx *ctx, size_t *seq_len, size_t *qual_l
   return FQGPU_OK;
 }
 
+extern "C" int fqgpu_encode_cancel(fqgpu_ctx *ctx) {
+  if (!ctx) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  ctx->hp_pending = false;
+  return fqgpu_sync(ctx);
+}
+
 extern "C" int fqgpu_encode_end(fqgpu_ctx *ctx, uint8_t *raw, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
                                 uint8_t *qual_out, size_t qual_cap, size_t *qual_len, uint16_t *readlens_out,
                                 uint16_t *n_count_out, uint16_t *n_pos_out, size_t n_pos_cap, size_t *n_pos_len) {

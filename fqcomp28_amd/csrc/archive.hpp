@@ -403,21 +403,34 @@ private:
  *  chunks are written as they come, by any number of threads, in any order. */
 class FastqWriter {
 public:
+  /** The chunks are written wherever they belong the moment they are ready, into `<mates1>.part` at its final size;
+   *  flush() -- every chunk is there -- gives the file its name.  A restore that fails (damaged block, farm aborted)
+   *  therefore leaves NO file under the requested name instead of a full-size one with zero-filled holes
+   *  (the reference's ordered writer left a short prefix, src/fastq_io.cpp:127-136): the partial file is removed. */
   FastqWriter(const path_t &mates1, std::vector<uint64_t> chunk_offsets)
-      : file_(mates1, PosFile::Mode::Create), at_(std::move(chunk_offsets)) {
+      : final_(mates1), part_(mates1.string() + ".part"), file_(part_, PosFile::Mode::Create), at_(std::move(chunk_offsets)) {
     if (at_.empty()) at_.push_back(0);
     file_.resize(at_.back());
+  }
+  ~FastqWriter() {
+    if (!done_) { std::error_code ec; std::filesystem::remove(part_, ec); }
   }
   void writeChunk(const FastqChunk &chunk) {
     if (chunk.idx + 1 >= at_.size() || at_[chunk.idx + 1] - at_[chunk.idx] != chunk.raw_data.size())
       throw std::runtime_error("FastqWriter: chunk " + std::to_string(chunk.idx) + " does not have the size the archive recorded");
     file_.writeAt(at_[chunk.idx], chunk.raw_data.data(), chunk.raw_data.size());
   }
-  void flush() {}
+  void flush() {
+    if (done_) return;
+    std::filesystem::rename(part_, final_);
+    done_ = true;
+  }
 
 private:
+  path_t final_, part_;
   PosFile file_;
   std::vector<uint64_t> at_;
+  bool done_ = false;
 };
 
 /** Dataset analysis (src/prepare.cpp:42-47): the tables of the first sample_size_bytes of the file, on the GPU */

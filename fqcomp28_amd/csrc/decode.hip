@@ -405,7 +405,7 @@ __device__ __forceinline__ void walk_positions(WalkT<COMPACT> &wk, LdsBits &br, 
   auto group_done = [&] {
     const unsigned kslot = (g >> 2) & 63u;
     // lane kslot of keep <- the four bytes (two instructions; compare, move, wait state and select are four)
-    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(keep) : "s"(fq_uniform(fq_sym_bytes<M>(acc))), "s"(fq_uniform(kslot)));
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(keep) : "s"(fq_uniform(fq_sym_bytes<M>(acc))), "s"(fq_uniform(kslot)));
     if (__builtin_expect(kslot == 63u, 0)) *reinterpret_cast<FQ_GLOBAL uint32_t *>(o + (g - 252u) + 4u * lane) = keep;  // (reads start anywhere: unaligned dwords)
   };
   const unsigned n4 = n & ~3u;

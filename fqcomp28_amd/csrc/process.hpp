@@ -85,9 +85,11 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
   // ... and so are its buffers: device scratch for chunks of the reading size, page-locked chunk and
   // stream buffers (half a second of hipMalloc / hipHostMalloc per worker that would otherwise sit
   // inside its first block)
-  std::vector<std::unique_ptr<CompressionWorkspace>> wksp(T);
+  // (declared BEFORE the workspaces: locals die in reverse order, so the handles -- whose destruction waits for
+  // everything they have queued -- go first and the page-locked buffers return to the pin cache after that)
   std::vector<FastqChunk> chunks(T);
   std::vector<CompressedBuffersDst> buffers(T);
+  std::vector<std::unique_ptr<CompressionWorkspace>> wksp(T);
   detail::runWorkers(T, [&](unsigned t) {
     wksp[t] = std::make_unique<CompressionWorkspace>(&meta, set.devices[t % set.devices.size()]);
     wksp[t]->reserve(set.reading_chunk_size);

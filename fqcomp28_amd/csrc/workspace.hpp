@@ -320,6 +320,15 @@ public:
     fqgpuCheck(fqgpu_encode_begin(ctx_, raw, chunk.raw_data.size(), parsed ? recs.data() : nullptr, recs.size(),
                                   FQGPU_F_WRITE_BACK_N, &R, &n_bases, &used),
                "encodeChunk");
+    // From here to fqgpu_encode_end the block is in flight: copies of chunk.raw_data and of `recs` may still be queued.
+    // Whatever throws in between (a chunk that ends inside a record, the header coder, a failing call) must not
+    // unwind past them: the guard waits for the handle before the local table dies and the caller's page-locked
+    // vectors can go back to the pin cache.
+    struct InFlight {
+      fqgpu_ctx *ctx;
+      bool armed = true;
+      ~InFlight() { if (armed) (void)fqgpu_encode_cancel(ctx); }
+    } in_flight{ctx_};
     clk.lap("begin");
     if (!parsed) {
       recs.resize(R);
@@ -351,6 +360,7 @@ public:
                                 reinterpret_cast<uint16_t *>(cbs.readlens.data()), reinterpret_cast<uint16_t *>(cbs.n_count.data() + cnt_at),
                                 reinterpret_cast<uint16_t *>(cbs.n_pos.data() + pos_at), n_pos_len, &n_pos_len),
                "encodeChunk");
+    in_flight.armed = false;
     clk.lap("end");
     cbs.original_size.n_records = static_cast<uint32_t>(R);
     cbs.original_size.total = static_cast<uint32_t>(chunk.raw_data.size());

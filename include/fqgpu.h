@@ -149,12 +149,16 @@ int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, const fqgpu
  *                         caller can size its buffers exactly (optional)
  *   fqgpu_encode_end      waits, delivers exactly what fqgpu_encode_block delivers; `raw` may be NULL
  *                         (no N -> A write-back).  Capacities below the stream sizes: FQGPU_E_OVERFLOW.
+ *   fqgpu_encode_cancel   drops the block in flight: waits until no copy or kernel of it touches the
+ *                         caller's buffers any more (a caller that unwinds between begin and end calls
+ *                         this before it lets go of the chunk and the stream buffers)
  * One block in flight per handle (a block begun and never ended is dropped by the next begin); every
  * other call on the handle waits for it. */
 int fqgpu_encode_begin(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, const fqgpu_rec *recs, size_t n_recs,
                        unsigned flags, size_t *n_recs_out, size_t *n_bases_out, size_t *used_len);
 int fqgpu_encode_records(fqgpu_ctx *ctx, fqgpu_rec *recs_out, size_t cap);
 int fqgpu_encode_wait(fqgpu_ctx *ctx, size_t *seq_len, size_t *qual_len, size_t *n_pos_len);
+int fqgpu_encode_cancel(fqgpu_ctx *ctx);
 int fqgpu_encode_end(fqgpu_ctx *ctx, uint8_t *raw, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
                      uint8_t *qual_out, size_t qual_cap, size_t *qual_len, uint16_t *readlens_out,
                      uint16_t *n_count_out, uint16_t *n_pos_out, size_t n_pos_cap, size_t *n_pos_len);

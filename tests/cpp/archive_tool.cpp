@@ -76,7 +76,7 @@ int main(int argc, char **argv) {
       }
       return 0;
     }
-    if ((argc == 4 && std::string(argv[1]) == "chunks") || (argc == 5 && std::string(argv[1]) == "rejoin")) {
+    if ((argc == 4 && std::string(argv[1]) == "chunks") || ((argc == 5 || argc == 6) && std::string(argv[1]) == "rejoin")) {
       const bool rejoin = argv[1][0] == 'r';
       FastqReader reader(argv[2], static_cast<std::size_t>(std::atoll(argv[rejoin ? 4 : 3])));
       std::vector<FastqChunk> chunks;
@@ -91,6 +91,8 @@ int main(int argc, char **argv) {
       if (rejoin) {
         FastqWriter writer(argv[3], at);
         for (std::size_t i = chunks.size(); i-- > 0;) writer.writeChunk(chunks[i]);
+        if (argc > 5 && argv[5][0] == 'a') return 3;  // "abandon": leave without flush() -- no output file may remain
+        writer.flush();
       }
       return 0;
     }

@@ -220,7 +220,11 @@ def test_reader_cuts_the_reference_chunks_without_parsing(tool, tmp_path, golden
     # reader -> writer identity with the chunks written last first (reference test/fastq_io_test.cpp:15-53)
     back = str(tmp_path / "back.fastq")
     assert subprocess.run([tool, "rejoin", path, back, "5000"], capture_output=True).returncode == 0
-    assert open(back, "rb").read() == raw.tobytes()
+    assert open(back, "rb").read() == raw.tobytes() and not os.path.exists(back + ".part")
+    # a writer that is abandoned before its flush() (a failed restore) leaves no file under either name
+    gone = str(tmp_path / "gone.fastq")
+    assert subprocess.run([tool, "rejoin", path, gone, "5000", "abandon"], capture_output=True).returncode == 3
+    assert not os.path.exists(gone) and not os.path.exists(gone + ".part")
     # a reading size below one record is an error, not a hang or an empty archive
     r = subprocess.run([tool, "chunks", path, str(biggest // 2)], capture_output=True, text=True)
     assert r.returncode == 1 and "smaller than one record" in r.stdout

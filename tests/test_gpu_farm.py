@@ -152,6 +152,8 @@ def test_a_damaged_block_ends_the_farm_with_an_error_not_a_hang(F, tool, tmp_pat
         r = subprocess.run([tool, "d", str(path), str(tmp_path / "bad.fastq"), "-t", "3"], capture_output=True, text=True, timeout=120)
         assert r.returncode == 1, (what, r.stdout, r.stderr)
         assert "fqc_tool:" in r.stderr
+        # a failed restore leaves nothing that looks like a restored file (the writer works in <name>.part and renames at the end)
+        assert not os.path.exists(tmp_path / "bad.fastq") and not os.path.exists(str(tmp_path / "bad.fastq") + ".part")
 
 
 def test_encode_from_an_unparsed_chunk_through_the_c_abi(F):
