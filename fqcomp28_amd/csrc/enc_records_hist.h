@@ -148,6 +148,16 @@ struct SymbolWalker {
   }
 };
 
+__device__ __forceinline__ unsigned sets_incl_scan_k1(unsigned v) {  // inclusive scan over the wave
+  const unsigned lane = fq_lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(v, d);
+    if (lane >= (unsigned)d) v += o;
+  }
+  return v;
+}
+
 // ------------------------------------------------------------------ K1: per-tile context histogram
 // Also leaves the key of every symbol in encode order, so that the partition pass is a plain
 // prefetchable linear scan: ckey[e] = ctx | sym << 8 (sequence: 10 bits) or ctx (quality: 13
@@ -267,11 +277,34 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
   }
 }
 
-// K1 for BOTH streams in one pass (tile-sorted path: the two streams share the tile geometry).  The
-// encoder as a whole is bound by instruction issue, and the two K1 launches each
-// walked the records, located every symbol and ran the same software pipeline: here that part is done
-// once per symbol and only the window load, the context arithmetic, the key store and the histogram
-// atomic are per stream.
+// K1 for BOTH streams in one pass (tile-sorted path: the two streams share the tile geometry), FOUR consecutive
+// positions of one read per lane.  The encoder is bound by the instructions it issues and by LDS cycles (DESIGN.md
+// section 8), and round 3's K1 spent 93 vector instructions and 11 LDS operations per 64 symbols on finding every
+// symbol's record, loading a window per symbol and stream and turning five bytes into codes through an LDS table.
+// Here a lane owns a QUAD: encode indices rs + 4 j .. rs + 4 j + 3 of ONE record (rs = the record's first encode index),
+// i.e. positions p_hi = L - 1 - 4 j down to p_hi - 3 (encode order runs backwards through a read,
+// src/fse_sequence.cpp:76-77,101; src/fse_quality.cpp:7,19).  Quads never straddle two reads, so one record search,
+// ONE 8-byte window per stream (positions p_hi - 7 .. p_hi) and one round of byte-parallel arithmetic serve four
+// symbols:
+//   sequence  the eight bases become eight 2-bit codes at once -- ((w >> 1) ^ (w >> 2)) & 0x03.. is 0 1 2 3 for A C G T
+//             and 0 for N, which the coder codes as A (src/fse_sequence.cpp:44) -- packed into a 16-bit string H, oldest
+//             position lowest; the key of the symbol at window byte k is (H >> 2 (k - 4)) & 0x3FF: context (the four
+//             bases in front of it, nearest in bits 7:6: src/fse_sequence.h:22-24) | symbol << 8 in ONE bit-field
+//             extract.  Bases in front of the read: the same string with 0xD7 (virtual T,C,C,T) shifted in.
+//             A byte that is no base at all is found by mapping the codes back to letters (v_perm) and comparing.
+//   quality   33 comes off all eight bytes at once; calcContext (src/fse_quality.h:40-44) per symbol from byte fields.
+// The last quad of a read may be short (L mod 4), and a quad at the edge of the wave's range belongs to two waves:
+// every symbol is masked by its encode index.  Full quads leave their keys with one 8-byte (+ one 4-byte) store.
+struct RecCache4 {
+  uint32_t start[65];   // rec_start of records r0 .. r0 + 64
+  uint32_t qpre[65];    // quads of this wave's range in the cached records before record k
+  uint32_t jlo[64];     // first quad of record k inside the wave's range
+  fqgpu_rec rec[64];
+};
+struct __attribute__((packed)) FqU64x1 { unsigned long long a; };  // eight bytes at any address
+
+constexpr int K1Q_DEPTH = 3;  // quad chunks (256 symbols) whose window loads are in flight
+
 __global__ void __launch_bounds__(256)
 k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
              const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
@@ -281,10 +314,7 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
   constexpr unsigned BS = SeqModel::B, BQ = QualModel::B;
   __shared__ uint32_t hist_s[BS];
   __shared__ uint32_t hist_q[BQ / 2];  // 16-bit counters, two per word (T <= 32768: they cannot wrap)
-  __shared__ RecCache rcache[4];  // one per wave
-  __shared__ uint8_t code_lut[256], sym_lut[256];
-  code_lut[threadIdx.x & 255u] = (uint8_t)fq_base_code(threadIdx.x & 255u);
-  sym_lut[threadIdx.x & 255u] = (uint8_t)fq_base_sym_n(threadIdx.x & 255u);  // bit 6: the byte is an N
+  __shared__ RecCache4 rcache[4];      // one per wave
   const unsigned tile = blockIdx.x;
   const unsigned e0 = tile * T;
   const unsigned e1 = min(e0 + T, n_sym);
@@ -296,61 +326,153 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
   const unsigned wb = min(e0 + wave * per, e1), we = min(wb + per, e1);
   bool bad_s = false, bad_q = false;
   if (wb < we) {
-    SymbolWalker w{recs, rec_start, fq_locate(rec_start, 0, R - 1, wb), R, &rcache[wave], 0};
-    SymBytes bs[K1_DEPTH], bq[K1_DEPTH];
-    unsigned bp[K1_DEPTH], br[K1_DEPTH];
-    unsigned lim = 0;
-    auto fetch = [&](int slot, unsigned eb2) {
-      const unsigned e2 = eb2 + lane;
-      const bool v2 = e2 < lim;
-      fqgpu_rec rec;
-      unsigned p;
-      w.locate(eb2, lim, e2, v2, rec, p, br[slot]);
-      bs[slot] = fq_load_sym_bytes<SeqModel>(raw, rec, p, v2);
-      bq[slot] = fq_load_sym_bytes<QualModel>(raw, rec, p, v2);
-      bp[slot] = p;
-    };
-    auto consume = [&](int slot, unsigned eb2) {
-      const unsigned e = eb2 + lane;
-      if (e < lim) {
-        unsigned ctx, sym;
-        fq_ctx_from_bytes<SeqModel>(bs[slot], bp[slot], ctx, sym, code_lut, sym_lut);
-        bad_s |= (sym & FQ_SYM_BAD_MASK) != 0;
-        if (sym & FQ_SYM_IS_N) atomicAdd(&n_cnt32[br[slot]], 1u);  // (rare) replaceAndEncodeNs's n_count, src/fse_sequence.cpp:35-51
-        ckey_seq[e] = (uint16_t)(ctx | ((sym & 3u) << 8));
-        atomicAdd(&hist_s[ctx], 1u);
-        fq_ctx_from_bytes<QualModel>(bq[slot], bp[slot], ctx, sym, code_lut, sym_lut);
-        bad_q |= sym >= (unsigned)QualModel::A;
-        ckey_qual[e] = (uint16_t)ctx;
-        csym_qual[e] = (uint8_t)(sym & 63u);
-        atomicAdd(&hist_q[ctx >> 1], 1u << (16u * (ctx & 1u)));
-      }
-    };
-    for (unsigned eb = wb; eb < we;) {
-      const unsigned covered = w.refill(w.r);
-      lim = covered >= we ? we : wb + ((covered - wb) & ~63u);
-#pragma unroll
-      for (int d = 0; d < K1_DEPTH - 1; d++)
-        if (eb + 64u * d < lim) fetch(d, eb + 64u * d);
-      for (; eb + 64u * (2 * K1_DEPTH - 2) < lim; eb += 64u * K1_DEPTH) {
-#pragma unroll
-        for (int d = 0; d < K1_DEPTH; d++) {
-          fetch((d + K1_DEPTH - 1) % K1_DEPTH, eb + 64u * (d + K1_DEPTH - 1));
-          consume(d, eb + 64u * d);
+    RecCache4 &rc = rcache[wave];
+    unsigned r0 = fq_locate(rec_start, 0, R - 1, wb);
+    for (;;) {
+      // ---- window of 64 records: starts, the quads of every record that fall into [wb, we), their prefix sums
+      fq_lds_wave_sync();  // nobody still reads the old window
+      rc.start[lane] = r0 + lane <= R ? rec_start[r0 + lane] : 0xFFFFFFFFu;
+      if (lane == 0) rc.start[64] = r0 + 64 <= R ? rec_start[r0 + 64] : 0xFFFFFFFFu;
+      if (r0 + lane < R) rc.rec[lane] = recs[r0 + lane];
+      fq_lds_wave_sync();
+      unsigned nq = 0, jl = 0;
+      {
+        const unsigned rs = rc.start[lane], rn = rc.start[lane + 1];
+        if (r0 + lane < R) {
+          const unsigned lo = max(rs, wb), hi = min(rn, we);
+          if (hi > lo) { jl = (lo - rs) >> 2; nq = ((hi - rs + 3u) >> 2) - jl; }
         }
       }
-      for (; eb < lim; eb += 64u * K1_DEPTH) {  // drain
+      const unsigned qincl = sets_incl_scan_k1(nq);
+      rc.qpre[lane] = qincl - nq;
+      rc.jlo[lane] = jl;
+      if (lane == 63) rc.qpre[64] = qincl;
+      fq_lds_wave_sync();
+      const unsigned Q = fq_uniform(rc.qpre[64]);
+      const unsigned covered = fq_uniform(rc.start[64]);
+      const unsigned nch = (Q + 63u) >> 6;
+
+      // ---- software pipeline over the chunks of 64 quads
+      unsigned long long ws[K1Q_DEPTH], wq[K1Q_DEPTH];  // windows, already shifted: byte k = position p_hi - 7 + k
+      unsigned ef[K1Q_DEPTH], vm[K1Q_DEPTH], mm[K1Q_DEPTH], rr[K1Q_DEPTH];  // first encode index, valid mask (4 bits), missing bytes, record
+      unsigned kc = 0;  // (uniform) cached record holding the first quad of the next chunk to be fetched
+      auto fetch = [&](int slot, unsigned c) {
+        const unsigned g0 = c << 6, g = g0 + lane;
+        const bool on = g < Q;
+        unsigned k = 0, kk = kc, qn;
+        for (;;) {
+          const unsigned qs = fq_uniform(rc.qpre[kk]);
+          qn = fq_uniform(rc.qpre[kk + 1]);
+          if (on && g >= qs && g < qn) k = kk;
+          if (qn >= g0 + 64u || kk == 63u) break;
+          kk++;
+        }
+        kc = qn > g0 + 64u ? kk : min(kk + 1u, 63u);
+        const fqgpu_rec rec = rc.rec[k];
+        const unsigned rs = rc.start[k], j = rc.jlo[k] + (g - rc.qpre[k]);
+        const unsigned L = on ? rec.len : 4u, j4 = on ? 4u * j : 0u;
+        const unsigned p_hi = L - 1u - j4;            // the quad's first symbol in encode order
+        const unsigned m = p_hi < 7u ? 7u - p_hi : 0u;  // window bytes in front of the read
+        const unsigned first = p_hi < 7u ? 0u : p_hi - 7u;
+        const unsigned long long a = reinterpret_cast<const FqU64x1 *>(raw + (on ? rec.seq_off : 0u) + first)->a;
+        const unsigned long long b = reinterpret_cast<const FqU64x1 *>(raw + (on ? rec.qual_off : 0u) + first)->a;
+        const unsigned e_first = rs + j4;
+        unsigned valid = 0;
 #pragma unroll
-        for (int d = 0; d < K1_DEPTH; d++) {
-          const unsigned cur = eb + 64u * d;
-          if (cur < lim) {
-            const unsigned nxt = cur + 64u * (K1_DEPTH - 1);
-            if (nxt < lim) fetch((d + K1_DEPTH - 1) % K1_DEPTH, nxt);
-            consume(d, cur);
+        for (unsigned i = 0; i < 4; i++) {
+          const unsigned e = e_first + i;
+          valid |= (on && i <= p_hi && e >= wb && e < we) ? 1u << i : 0u;
+        }
+        ws[slot] = a; wq[slot] = b; ef[slot] = e_first; vm[slot] = valid; mm[slot] = m; rr[slot] = r0 + k;
+      };
+      auto consume = [&](int slot) {
+        const unsigned valid = vm[slot], sh = 8u * mm[slot], e_first = ef[slot];
+        if (!valid) return;
+        // -------- sequence
+        const unsigned long long w = ws[slot] << sh;   // byte k = position p_hi - 7 + k (0 in front of the read)
+        const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+        const unsigned clo = ((lo >> 1) ^ (lo >> 2)) & 0x03030303u, chi = ((hi >> 1) ^ (hi >> 2)) & 0x03030303u;
+        auto pack4 = [](unsigned c) { c |= c >> 6; c |= c >> 12; return c & 0xFFu; };  // four byte codes -> 8 bits
+        unsigned H = pack4(clo) | (pack4(chi) << 8);
+        H |= 0xD700u >> (16u - 2u * mm[slot]);          // virtual T,C,C,T in front of the read (mm = 0: nothing)
+        // bytes that are not A C G T: N (counted, coded as A) or no base at all
+        const unsigned diff = (__builtin_amdgcn_perm(0u, 0x54474341u, chi) ^ hi);
+        unsigned k16[4];
+#pragma unroll
+        for (unsigned i = 0; i < 4; i++) k16[i] = (H >> (2u * (3u - i))) & 0x3FFu;
+        if (diff) {
+#pragma unroll
+          for (unsigned i = 0; i < 4; i++) {
+            const unsigned d = (diff >> (8u * (3u - i))) & 0xFFu;
+            if (d && ((valid >> i) & 1u)) {
+              if (((hi >> (8u * (3u - i))) & 0xFFu) == 'N') atomicAdd(&n_cnt32[rr[slot]], 1u);  // (rare) replaceAndEncodeNs's n_count, src/fse_sequence.cpp:35-51
+              else bad_s = true;
+            }
+          }
+        }
+        // -------- quality
+        const unsigned long long q33 = (wq[slot] - 0x2121212121212121ull) << sh;  // (a byte below 33 borrows from its UPPER neighbour only: a later position, and then the block is refused anyway)
+        const unsigned ql = (unsigned)q33, qh = (unsigned)(q33 >> 32);
+        // byte fields 1 .. 7: b[t] = quality at position p_hi - 7 + t
+        const unsigned b1 = (ql >> 8) & 0xFFu, b2 = (ql >> 16) & 0xFFu, b3 = ql >> 24, b4 = qh & 0xFFu, b5 = (qh >> 8) & 0xFFu,
+                       b6 = (qh >> 16) & 0xFFu, b7 = qh >> 24;
+        const unsigned qs_[4] = {b7, b6, b5, b4};   // symbol of quad entry i
+        const unsigned qa[4] = {b6, b5, b4, b3};    // position - 1
+        const unsigned qb[4] = {b5, b4, b3, b2};    // position - 2
+        const unsigned qc[4] = {b4, b3, b2, b1};    // position - 3
+        unsigned cq[4];
+#pragma unroll
+        for (unsigned i = 0; i < 4; i++) {
+          cq[i] = ((((qb[i] > qc[i] ? qb[i] : qc[i]) << 6) + qa[i]) & 0xFFFu) | ((qb[i] == qc[i]) ? 0x1000u : 0u);
+          bad_q |= ((valid >> i) & 1u) && qs_[i] >= (unsigned)QualModel::A;
+        }
+        // -------- keys out, histograms
+        if (valid == 0xFu) {
+          struct __attribute__((packed)) P8 { uint32_t a, b; };
+          struct __attribute__((packed)) P4 { uint32_t a; };
+          *reinterpret_cast<P8 *>(ckey_seq + e_first) = P8{k16[0] | (k16[1] << 16), k16[2] | (k16[3] << 16)};
+          *reinterpret_cast<P8 *>(ckey_qual + e_first) = P8{cq[0] | (cq[1] << 16), cq[2] | (cq[3] << 16)};
+          *reinterpret_cast<P4 *>(csym_qual + e_first) = P4{(qs_[0] & 63u) | ((qs_[1] & 63u) << 8) | ((qs_[2] & 63u) << 16) | ((qs_[3] & 63u) << 24)};
+#pragma unroll
+          for (unsigned i = 0; i < 4; i++) {
+            atomicAdd(&hist_s[k16[i] & 0xFFu], 1u);
+            atomicAdd(&hist_q[cq[i] >> 1], 1u << (16u * (cq[i] & 1u)));
+          }
+        } else {
+#pragma unroll
+          for (unsigned i = 0; i < 4; i++)
+            if ((valid >> i) & 1u) {
+              ckey_seq[e_first + i] = (uint16_t)k16[i];
+              ckey_qual[e_first + i] = (uint16_t)cq[i];
+              csym_qual[e_first + i] = (uint8_t)(qs_[i] & 63u);
+              atomicAdd(&hist_s[k16[i] & 0xFFu], 1u);
+              atomicAdd(&hist_q[cq[i] >> 1], 1u << (16u * (cq[i] & 1u)));
+            }
+        }
+      };
+#pragma unroll
+      for (int d = 0; d < K1Q_DEPTH - 1; d++)
+        if ((unsigned)d < nch) fetch(d, (unsigned)d);
+      unsigned c = 0;
+      for (; c + 2u * (K1Q_DEPTH - 1) < nch; c += K1Q_DEPTH) {  // steady state: straight-line fetch / consume
+#pragma unroll
+        for (int d = 0; d < K1Q_DEPTH; d++) {
+          fetch((d + K1Q_DEPTH - 1) % K1Q_DEPTH, c + d + (K1Q_DEPTH - 1));
+          consume(d);
+        }
+      }
+      for (; c < nch; c += K1Q_DEPTH) {  // drain
+#pragma unroll
+        for (int d = 0; d < K1Q_DEPTH; d++) {
+          const unsigned cur = c + d;
+          if (cur < nch) {
+            if (cur + (K1Q_DEPTH - 1) < nch) fetch((d + K1Q_DEPTH - 1) % K1Q_DEPTH, cur + (K1Q_DEPTH - 1));
+            consume(d);
           }
         }
       }
-      eb = lim;
+      if (covered >= we || r0 + 64u >= R) break;
+      r0 += 64u;
     }
   }
   if (bad_s) atomicOr(&res->s[0].bad_symbol, 1u);

@@ -33,6 +33,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #ifdef FQGPU_EXPERIMENTS
@@ -90,11 +91,21 @@ static unsigned fq_debug_skip() {
 }
 static int fq_debug_k1() { const char *e = getenv("FQGPU_DEBUG_K1"); return e ? atoi(e) : 0; }
 static bool fq_debug_flag(const char *name) { return getenv(name) != nullptr; }
+// FQGPU_DEBUG_SKIPK=name,name,...: single kernels that are not launched (k1 k3s k3q setfunc resolve emit scan stage1 heads qresolve walk2 k6s k6q k2s k2q)
+static bool fq_debug_skipk(const char *name) {
+  const char *e = getenv("FQGPU_DEBUG_SKIPK");
+  if (!e) return false;
+  const size_t n = strlen(name);
+  for (const char *p = e; (p = strstr(p, name)) != nullptr; p += n)
+    if ((p == e || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+  return false;
+}
 #else
 static constexpr int fq_debug_no_sym(int) { return 0; }
 static constexpr unsigned fq_debug_skip() { return 0u; }
 static constexpr int fq_debug_k1() { return 0; }
 static constexpr bool fq_debug_flag(const char *) { return false; }
+static constexpr bool fq_debug_skipk(const char *) { return false; }
 #endif
 
 // true: both streams take the tile-sorted path, so K1 can run once for both (k_tile_hist2)
@@ -214,7 +225,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), ckey, csym, res,
                      fq_debug_k1());
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");  dbg_off = (dbg_mask & 2u) != 0;
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");  dbg_off = (dbg_mask & 2u) != 0 || fq_debug_skipk(M::STREAM ? "k2q" : "k2s");
   if (!dbg_off) hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
                      sc.tile_hist.as<uint32_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
   if (!dbg_off) hipLaunchKernelGGL(k_group_prefix, dim3((B + 255) / 256), dim3(256), 0, st, sc.group_sum.as<uint32_t>(), n_groups, B, arrays);
@@ -224,7 +235,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                      sc.tile_hist.as<uint32_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B,
                      sc.tile_base.as<uint32_t>());
   FQ_SPAN_END();
-  FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");  dbg_off = (dbg_mask & 4u) != 0;
+  FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");  dbg_off = (dbg_mask & 4u) != 0 || fq_debug_skipk(M::STREAM ? "k3q" : "k3s");
   SeqBatchDesc bd;
   bd.start = sc.seq_bdesc.as<uint32_t>();
   bd.pre = reinterpret_cast<uint16_t *>(bd.start + (size_t)(n_ptiles + 1) * SeqModel::B);
@@ -271,12 +282,12 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     const uint16_t *pow = nullptr;  // power tables for this segment length (uniform segments), if the handle has them
     for (unsigned i = 0; i < FQ_SEQ_POW_SETS; i++)
       if (tab.seq_pow[i] && tab.seq_pow_S[i] == seq_S) pow = tab.seq_pow[i];
-    static const bool dbg_skip = fq_debug_flag("FQGPU_DEBUG_SKIP_SEQ_CHAIN");  // timing experiment only: wrong output
+    const bool dbg_skip = fq_debug_flag("FQGPU_DEBUG_SKIP_SEQ_CHAIN");  // timing experiment only: wrong output
     if (!dbg_off) hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, Q, gmin, wpg * rounds, plan);
     FQ_SPAN_END();
     FQ_SPAN_BEGIN("seq.setfunc");
     if (!dbg_skip) {
-      if (dbg_off) {
+      if (dbg_off || fq_debug_skipk("setfunc")) {
       } else if (two)
         hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(min(max_fitems, ctx->setfunc_wgs ? ctx->setfunc_wgs : ctx->n_cus)), dim3(SETS_WAVES2 * 64),
                            32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2,
@@ -286,7 +297,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                            8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1,
                            next_stride, pow, next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 5 * (B + 1));
       FQ_SPAN_END();
-      FQ_SPAN_BEGIN("seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
+      FQ_SPAN_BEGIN("seq.resolve");  dbg_off = (dbg_mask & 8u) != 0 || fq_debug_skipk("resolve");
       if (!dbg_off) {
         if (tab.max_log <= 11)
           hipLaunchKernelGGL(k_seq_resolve<32>, dim3(1), dim3(SEQ_RESOLVE_THREADS), 0, st, plan, tab.logs, fbuf, seq_fstride, Q, gmin, cbuf, item_entry, entry);
@@ -294,7 +305,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
           hipLaunchKernelGGL(k_seq_resolve<64>, dim3(1), dim3(SEQ_RESOLVE_THREADS), 0, st, plan, tab.logs, fbuf, seq_fstride, Q, gmin, cbuf, item_entry, entry);
       }
       FQ_SPAN_END();
-      FQ_SPAN_BEGIN("seq.chains");  dbg_off = (dbg_mask & 8u) != 0;
+      FQ_SPAN_BEGIN("seq.chains");  dbg_off = (dbg_mask & 8u) != 0 || fq_debug_skipk("emit");
       if (!dbg_off) hipLaunchKernelGGL(k_seq_emit, dim3(max_eitems), dim3(64), 8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(),
                          sc.out16.as<uint16_t>(), arrays, plan, tab.ct, tab.ct_off, tab.next1, next_stride, seq_S,
                          entry, final_state, res);
@@ -310,10 +321,10 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     if (M::STREAM == 1) { b->diag_cls = sa.cls; b->diag_n_segs = arrays + B + (B + 1) + B; }  // seg_base[B]
     uint16_t *fbuf = sc.seq_fbuf.as<uint16_t>();
     const unsigned cand_grid = min(gen_max_segs / (64 / SEG_SLOT) + 1, 32u * ctx->n_cus);
-    if (!dbg_off) hipLaunchKernelGGL(k_seg_scan<M>, dim3((gen_max_segs + 3) / 4), dim3(256), 0, st, sc.sorted_sym.as<uint8_t>(),
+    if (!dbg_off && !fq_debug_skipk("scan")) hipLaunchKernelGGL(k_seg_scan<M>, dim3((gen_max_segs + 3) / 4), dim3(256), 0, st, sc.sorted_sym.as<uint8_t>(),
                        arrays, tab.reset_mask, tab.norm, tab.logs, S, sa);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.stage1" : "seq.stage1");  dbg_off = (dbg_mask & 8u) != 0;
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.stage1" : "seq.stage1");  dbg_off = (dbg_mask & 8u) != 0 || fq_debug_skipk("stage1");
     if (dbg_off) {
     } else if (tab.max_log <= 11)
       hipLaunchKernelGGL((k_seg_stage1<M, 32>), dim3(max_items + cand_grid + gen_pbase + B), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
@@ -322,12 +333,12 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
       hipLaunchKernelGGL((k_seg_stage1<M, 64>), dim3(max_items + cand_grid + gen_pbase + B), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                          sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, max_items, cand_grid, gen_pbase, gen_fstride, sa, fbuf, res);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.heads" : "seq.heads");  dbg_off = (dbg_mask & 8u) != 0;
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.heads" : "seq.heads");  dbg_off = (dbg_mask & 8u) != 0 || fq_debug_skipk("heads");
     if (!dbg_off)
       hipLaunchKernelGGL(k_seg_heads<M>, dim3(cand_grid), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(), arrays, tab.ct,
                          tab.ct_off, S, gen_fstride, sa, fbuf);
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.resolve" : "seq.resolve");  dbg_off = (dbg_mask & 8u) != 0;
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.resolve" : "seq.resolve");  dbg_off = (dbg_mask & 8u) != 0 || fq_debug_skipk("qresolve");
     if (!dbg_off) {
       ItemArrays ia;
       ia.has_g = reinterpret_cast<uint32_t *>(sab + ia_has_g);
@@ -342,14 +353,14 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
                          gen_pbase, gen_fstride, sa, ia);
     }
     FQ_SPAN_END();
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk2" : "seq.walk2");  dbg_off = (dbg_mask & 8u) != 0;
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.walk2" : "seq.walk2");  dbg_off = (dbg_mask & 8u) != 0 || fq_debug_skipk("walk2");
     if (!dbg_off) hipLaunchKernelGGL((k_seg_walk<M, 2>), dim3(max_items), dim3(64), lds_ct, st, sc.sorted_sym.as<uint8_t>(),
                        sc.out16.as<uint16_t>(), arrays, tab.ct, tab.ct_off, final_state, S, sa, res);
   }
   FQ_SPAN_END();
   if (tile_path) {
     // the stream starts from zeros (words shared by two tiles are OR-ed into), the look-back from clean flags
-    FQ_SPAN_BEGIN(M::STREAM ? "qual.gatherpack" : "seq.gatherpack");  dbg_off = (dbg_mask & 16u) != 0;
+    FQ_SPAN_BEGIN(M::STREAM ? "qual.gatherpack" : "seq.gatherpack");  dbg_off = (dbg_mask & 16u) != 0 || fq_debug_skipk(M::STREAM ? "k6q" : "k6s");
     if (!dbg_off) {
       FQ_HIP(hipMemsetAsync(out_dev, 0, cap + 64, st));
       FQ_HIP(hipMemsetAsync(sync_base, 0, sync_counter_off + 16, st));
@@ -624,7 +635,7 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
     const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15;
     uint16_t *kq = lane.enc[1].keys.as<uint16_t>();
     FQ_SPAN_BEGIN("tile_hist2");
-    hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R, n_sym, TS_TILE,
+    if (!fq_debug_skipk("k1")) hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R, n_sym, TS_TILE,
                        lane.enc[0].tile_hist.as<uint32_t>(), lane.enc[0].keys.as<uint16_t>(), lane.enc[1].tile_hist.as<uint32_t>(), kq,
                        reinterpret_cast<uint8_t *>(kq + n_pad), n_cnt32, b->result);
     FQ_SPAN_END();
@@ -632,7 +643,7 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
   FQ_HIP(hipEventRecord(lane.ev_fork, lane.st_seq));
   FQ_HIP(hipStreamWaitEvent(lane.st_qual, lane.ev_fork, 0));
   // timing experiments only (wrong output): one stream at a time
-  static const bool dbg_no_qual = fq_debug_flag("FQGPU_DEBUG_SKIP_QUAL"), dbg_no_seq = fq_debug_flag("FQGPU_DEBUG_SKIP_SEQ");
+  const bool dbg_no_qual = fq_debug_flag("FQGPU_DEBUG_SKIP_QUAL"), dbg_no_seq = fq_debug_flag("FQGPU_DEBUG_SKIP_SEQ");
   if (!dbg_no_qual && (rc = encode_stream<QualModel>(ctx, lane, lane.st_qual, b, rec_start, b->qual, b->qual_cap, flags))) return rc;
   if (!dbg_no_seq && (rc = encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, b->seq, b->seq_cap, flags))) return rc;
   FQ_HIP(hipEventRecord(lane.ev_join, lane.st_qual));
