@@ -303,7 +303,10 @@ struct RecCache4 {
 };
 struct __attribute__((packed)) FqU64x1 { unsigned long long a; };  // eight bytes at any address
 
-constexpr int K1Q_DEPTH = 3;  // quad chunks (256 symbols) whose window loads are in flight
+#ifndef FQ_K1Q_DEPTH
+#define FQ_K1Q_DEPTH 3
+#endif
+constexpr int K1Q_DEPTH = FQ_K1Q_DEPTH;  // quad chunks (256 symbols) whose window loads are in flight
 
 __global__ void __launch_bounds__(256)
 k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,

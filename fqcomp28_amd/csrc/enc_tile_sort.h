@@ -21,8 +21,13 @@ constexpr unsigned TS_TILE = 32768;    // symbols per tile (lpos16 and the 16-bi
 constexpr unsigned TS_BATCH = 4096;    // symbols ranked between two workgroup barriers (K3: 72 KB of LDS, two workgroups per CU)
 constexpr unsigned TS_THREADS = 512;   // K3
 constexpr unsigned TS_WAVES = TS_THREADS / 64;
-constexpr unsigned TS_GP_THREADS = 256;  // K6: 76 KB of LDS, two workgroups per CU
-constexpr unsigned TS_SUB = TS_GP_THREADS * PACK_PER_THREAD;  // symbols packed per round of K6 (4096)
+#ifndef FQ_K6_THREADS
+#define FQ_K6_THREADS 512
+#endif
+constexpr unsigned TS_GP_THREADS = FQ_K6_THREADS;  // K6: 78 KB of LDS, two workgroups per CU = 16 waves (256 threads: 8 waves per CU, 2.6 % slower on the step)
+constexpr unsigned TS_GP_PPT = 4096 / TS_GP_THREADS;  // symbols a thread packs per round: 16 or 8
+constexpr unsigned TS_SUB = TS_GP_THREADS * TS_GP_PPT;  // symbols packed per round of K6 (4096)
+static_assert(TS_GP_PPT == 16 || TS_GP_PPT == 8, "K6 packs 16 or 8 symbols per thread and round");
 static_assert(TS_TILE % TS_BATCH == 0 && TS_TILE % TS_SUB == 0 && TS_SUB % PACK_TILE == 0, "tile geometry");
 
 // phase timing of the two kernels (experiments build only): g_ts_prof[8 * kernel + phase] += wall clock ticks of workgroup thread 0
@@ -107,17 +112,26 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   constexpr unsigned NCHUNK = B / 64;  // 64 contexts per chunk: 128 (quality) / 4 (sequence)
   __shared__ uint32_t cursor32[B / 2];  // 16-bit cursors (local positions), two per word
   __shared__ __attribute__((aligned(16))) uint8_t lsym[TS_TILE + 64];  // the tile's symbols in sorted order (+ a dump for idle lanes)
-  // two batch buffers: batch j is ranked while the loading waves write batch j + 1 into the other one --
-  // from REGISTERS they filled one batch earlier -- and request batch j + 2 into those registers: the
-  // loads stay in flight across the barrier (it waits for LDS only), so nobody ever sits at a barrier
-  // waiting for global memory (with loads that went straight to LDS the ranking wave waited out a
-  // memory round trip per batch: half of this kernel).  The run map lives in the same bytes: it is
-  // built when the last batch has been ranked.
+  // two batch buffers: batch j is ranked while the other seven waves (a) finish batch j - 1 -- the ranking wave left
+  // every symbol's POSITION in the slot its key came from; they put the symbols to their places in lsym and store the
+  // positions (lpos16: 16 bytes per thread) --, (b) write batch j + 1 into the buffer that has just become free,
+  // from REGISTERS they filled one batch earlier, and (c) request batch j + 2 into those registers: the loads stay
+  // in flight across the barrier (it waits for LDS only), so nobody ever sits at a barrier waiting for global
+  // memory.  The ranking wave -- ONE wave has to do it: the rank comes from lane-ordered atomics in program order --
+  // is left with three LDS operations per 64 symbols (key, atomic, position); round 3's also read the symbol,
+  // placed it and stored the position to global memory: half of this kernel's time was that one wave's loop.
+  // The run map lives in the same bytes: it is built when the last batch has been ranked.
   constexpr unsigned NBUF = 2;
-  constexpr unsigned KB_BYTES = NBUF * (TS_BATCH / 8) * 16, SB_BYTES = QUAL ? NBUF * (TS_BATCH / 16) * 16 : 16;
+#ifndef FQ_K3_SEQ_RANKER_PLACES
+#define FQ_K3_SEQ_RANKER_PLACES 0
+#endif
+  // sequence stream (FQ_K3_SEQ_RANKER_PLACES): the symbol is in the key, the ranking wave places it itself -- no symbol
+  // buffers, 50 KB of LDS, three workgroups per CU instead of two
+  constexpr bool PLACE = QUAL || !FQ_K3_SEQ_RANKER_PLACES;   // the loaders place the symbols
+  constexpr unsigned KB_BYTES = NBUF * (TS_BATCH / 8) * 16, SB_BYTES = PLACE ? NBUF * (TS_BATCH / 8) * 8 : 16;
   __shared__ __attribute__((aligned(16))) uint8_t stage_raw[(KB_BYTES + SB_BYTES) > sizeof(TsRunMap) ? (KB_BYTES + SB_BYTES) : sizeof(TsRunMap)];
   uint4 (*kb4)[TS_BATCH / 8] = reinterpret_cast<uint4 (*)[TS_BATCH / 8]>(stage_raw);
-  uint4 (*sb4)[QUAL ? TS_BATCH / 16 : 1] = reinterpret_cast<uint4 (*)[QUAL ? TS_BATCH / 16 : 1]>(stage_raw + KB_BYTES);
+  uint2 (*sb8)[PLACE ? TS_BATCH / 8 : 1] = reinterpret_cast<uint2 (*)[PLACE ? TS_BATCH / 8 : 1]>(stage_raw + KB_BYTES);  // the symbols of key piece p: eight bytes
   TsRunMap &rm = *reinterpret_cast<TsRunMap *>(stage_raw);
   __shared__ unsigned wsum[TS_WAVES], s_cnt[NCHUNK < 2 ? 2 : NCHUNK], s_nruns, s_max;
   __shared__ uint32_t dummy[64];  // where the lanes of the combining ranker that are no run heads send their (empty) atomics
@@ -159,32 +173,70 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   TS_PROF(PS + 0);
   // ---- ranking, batch by batch
   const unsigned nbatch = (nt + TS_BATCH - 1) / TS_BATCH;
-  // the loading waves (448 threads): thread t < 512 owns one 16-byte piece of a batch's keys, thread
-  // 512 <= t' < 768 (quality) one piece of its symbols -- at most two pieces per thread
-  static_assert(TS_BATCH / 8 == 512 && TS_BATCH / 16 == 256, "piece ownership below assumes a 4096-symbol batch");
+  // the loading waves (448 threads): thread mt owns the 16-byte key pieces mt and mt + 448 (eight symbols each) of
+  // every batch and the eight symbol bytes that go with each -- it loads them, deposits them, and later finishes
+  // exactly those symbols, so no two threads ever touch one piece between two barriers
+  static_assert(TS_BATCH / 8 == 512, "piece ownership below assumes a 4096-symbol batch");
+  constexpr unsigned NL = TS_THREADS - 64;
+  static_assert(2 * NL >= TS_BATCH / 8, "at most two pieces per loading thread");
   const unsigned mt = tid - 64;  // loader thread number (valid for tid >= 64)
-  uint4 rk0 = make_uint4(0, 0, 0, 0), rk1 = rk0, rs0 = rk0;
+  const bool two = mt + NL < TS_BATCH / 8;
+  uint4 rk0 = make_uint4(0, 0, 0, 0), rk1 = rk0;
+  uint2 rs0 = make_uint2(0, 0), rs1 = rs0;
+  auto syms_of = [](const uint4 k) {  // sequence stream: the symbol is bits 9:8 of the key
+    auto two_of = [](unsigned w) { return ((w >> 8) & 0xFFu) | ((w >> 24) << 8); };
+    return make_uint2(two_of(k.x) | (two_of(k.y) << 16), two_of(k.z) | (two_of(k.w) << 16));
+  };
   auto request = [&](unsigned j) {  // batch j -> registers (loaders)
     const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + e0 + j * TS_BATCH);  // 16-byte aligned; arrays are padded by a batch
+    const uint2 *gs = reinterpret_cast<const uint2 *>(csym + e0 + j * TS_BATCH);
     rk0 = gk[mt];
-    if (mt + 448 < 512) rk1 = gk[mt + 448];
-    if (QUAL && mt < 256) rs0 = reinterpret_cast<const uint4 *>(csym + e0 + j * TS_BATCH)[mt];
+    if (two) rk1 = gk[mt + NL];
+    if (QUAL) { rs0 = gs[mt]; if (two) rs1 = gs[mt + NL]; }
   };
   auto deposit = [&](unsigned j) {  // registers -> LDS buffer of batch j (loaders)
     kb4[j % NBUF][mt] = rk0;
-    if (mt + 448 < 512) kb4[j % NBUF][mt + 448] = rk1;
-    if (QUAL && mt < 256) sb4[j % NBUF][mt] = rs0;
+    if (PLACE) sb8[j % NBUF][mt] = QUAL ? rs0 : syms_of(rk0);
+    if (two) { kb4[j % NBUF][mt + NL] = rk1; if (PLACE) sb8[j % NBUF][mt + NL] = QUAL ? rs1 : syms_of(rk1); }
   };
-  // Barrier of the batch loop: LDS traffic only.  __syncthreads() also drains vmcnt, i.e. the ranking
-  // wave would wait at every barrier for its position stores (fire and forget) to reach memory and the
-  // loaders for the batch they have just requested.
+  // batch j has been ranked: its buffer holds positions where the keys were.  Symbols to their places, positions out.
+  auto finish_piece = [&](unsigned j, unsigned piece) {
+    const unsigned i0 = piece * 8u, nb = min(TS_BATCH, nt - j * TS_BATCH);
+    if (i0 >= nb) return;
+    const uint4 p4 = kb4[j % NBUF][piece];
+    const uint2 s2 = PLACE ? sb8[j % NBUF][piece] : make_uint2(0, 0);
+    const unsigned pw[4] = {p4.x, p4.y, p4.z, p4.w};
+    uint16_t *gpos = lpos16 + e0 + j * TS_BATCH + i0;
+    if (i0 + 8u <= nb) {
+      *reinterpret_cast<uint4 *>(gpos) = p4;
+      if (PLACE)
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++)
+          lsym[(pw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu] = (uint8_t)(((k < 4 ? s2.x : s2.y) >> (8u * (k & 3u))) & 0xFFu);
+    } else {
+#pragma unroll
+      for (unsigned k = 0; k < 8; k++)
+        if (i0 + k < nb) {
+          const unsigned pos = (pw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+          gpos[k] = (uint16_t)pos;
+          if (PLACE) lsym[pos] = (uint8_t)(((k < 4 ? s2.x : s2.y) >> (8u * (k & 3u))) & 0xFFu);
+        }
+    }
+  };
+  auto finish = [&](unsigned j) {
+    finish_piece(j, mt);
+    if (two) finish_piece(j, mt + NL);
+  };
+  // Barrier of the batch loop: LDS traffic only.  __syncthreads() also drains vmcnt, i.e. the loaders would wait at
+  // every barrier for the batch they have just requested and for their position stores (fire and forget).
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   {  // batch 0 by everybody, straight to LDS
     const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + e0);
-    for (unsigned i = tid; i < TS_BATCH / 8; i += TS_THREADS) kb4[0][i] = gk[i];
-    if (QUAL) {
-      const uint4 *gs = reinterpret_cast<const uint4 *>(csym + e0);
-      for (unsigned i = tid; i < TS_BATCH / 16; i += TS_THREADS) sb4[0][i] = gs[i];
+    const uint2 *gs = reinterpret_cast<const uint2 *>(csym + e0);
+    for (unsigned i = tid; i < TS_BATCH / 8; i += TS_THREADS) {
+      const uint4 k = gk[i];
+      kb4[0][i] = k;
+      if (PLACE) sb8[0][i] = QUAL ? gs[i] : syms_of(k);
     }
   }
   if (wave != 0 && nbatch > 1) request(1);
@@ -197,20 +249,20 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   // only for such tiles; the ranks are the same numbers either way.
   const bool combine = s_max * 8u >= nt;
   const unsigned long long lanes_le = (2ull << lane) - 1ull;
-  for (unsigned j = 0; j < nbatch; j++) {
-    if (wave == 0 && combine) {
+  for (unsigned j = 0; j <= nbatch; j++) {  // (one period more than there are batches: the last batch is finished in it)
+    if (wave == 0 && j < nbatch && combine) {
       const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j % NBUF]);
-      const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j % NBUF]);
+      const uint8_t *sbb = reinterpret_cast<const uint8_t *>(sb8[j % NBUF]);
       uint16_t *gpos = lpos16 + e0 + j * TS_BATCH;
       const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
       constexpr unsigned G = 4;  // (four iterations in flight: eight cost 22 more VGPRs for the whole kernel, which every tile pays)
       for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // wave-uniform trip count, branch-free, as below
-        unsigned key[G], pos[G], sy[G], head_of[G];
+        unsigned key[G], pos[G], head_of[G], sy[G];
 #pragma unroll
         for (unsigned g = 0; g < G; g++) {
           const unsigned i = cb + 64 * g + lane;
           key[g] = kb[i];
-          sy[g] = QUAL ? (unsigned)sb[i] : key[g] >> 8;
+          sy[g] = PLACE ? (unsigned)sbb[i] : key[g] >> 8;
         }
 #pragma unroll
         for (unsigned g = 0; g < G; g++) {
@@ -227,40 +279,36 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
           pos[g] = (atomicAdd(a, act ? (nx - lane) << sh : 0u) >> sh) & 0xFFFFu;
           head_of[g] = h;
         }
+        // (this ranker finishes its symbols itself: its loop is short, and on such tiles -- long runs of one context --
+        // the loaders' share of the work would be the longer one: constant data 4 %, real reads 2 % slower when split)
 #pragma unroll
         for (unsigned g = 0; g < G; g++) {
           const unsigned i = cb + 64 * g + lane;
           const unsigned p = (unsigned)__shfl((int)pos[g], (int)head_of[g]) + (lane - head_of[g]);
-          gpos[i] = (uint16_t)p;
+          gpos[i] = (uint16_t)p;  // (beyond the batch: garbage that lands behind the tile's part of lpos16)
           lsym[i < nb ? p : TS_TILE + lane] = (uint8_t)sy[g];
         }
       }
-    } else if (wave == 0) {
-      const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j % NBUF]);
-      const uint8_t *sb = reinterpret_cast<const uint8_t *>(sb4[j % NBUF]);
-      uint16_t *gpos = lpos16 + e0 + j * TS_BATCH;  // the ranking wave stores the positions itself: 128 contiguous bytes per instruction
+    } else if (wave == 0 && j < nbatch) {
+      uint16_t *kb = reinterpret_cast<uint16_t *>(kb4[j % NBUF]);
       const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
       // Wave-uniform trip count with the bound checked inside: with a per-lane trip count the
       // compiler's unrolling lets low lanes run ahead of high lanes by a whole group of iterations,
       // and the rank is only right if iteration k of every lane precedes iteration k + 1 of any lane.
       // Software-pipelined by hand, G iterations at a time: all key reads, then all atomics
-      // (the LDS executes them in program order), then all stores -- three LDS round trips per group
+      // (the LDS executes them in program order), then all position writes -- three LDS round trips per group
       // instead of three per iteration: the loop is a pure latency chain and ONE wave ranks a tile.
-      // Branch-free: a lane beyond the batch adds 0 to cursor word 0 and stores into the spare bytes
-      // behind the tile -- behind a branch hipcc waits for every atomic's return value before it
-      // issues the next one (s_waitcnt lgkmcnt(0) in each arm), which is the whole latency again.
+      // Branch-free: a lane beyond the batch adds 0 to cursor word 0 (its position is never used) -- behind a
+      // branch hipcc waits for every atomic's return value before it issues the next one (s_waitcnt lgkmcnt(0)
+      // in each arm), which is the whole latency again.
       constexpr unsigned G = 8;
 #ifdef FQGPU_EXPERIMENTS
       const unsigned long long tr0 = wall_clock64();
 #endif
-      for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // nothing in here waits for global memory
-        unsigned key[G], pos[G], sy[G];
+      for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // nothing in here touches global memory
+        unsigned key[G], pos[G];
 #pragma unroll
-        for (unsigned g = 0; g < G; g++) {
-          const unsigned i = cb + 64 * g + lane;  // < TS_BATCH: the buffers hold a whole batch
-          key[g] = kb[i];
-          sy[g] = QUAL ? (unsigned)sb[i] : key[g] >> 8;
-        }
+        for (unsigned g = 0; g < G; g++) key[g] = kb[cb + 64 * g + lane];  // (< TS_BATCH: the buffers hold a whole batch)
 #pragma unroll
         for (unsigned g = 0; g < G; g++) {
           const bool on = cb + 64 * g + lane < nb;
@@ -270,15 +318,17 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
 #pragma unroll
         for (unsigned g = 0; g < G; g++) {
           const unsigned i = cb + 64 * g + lane;
-          gpos[i] = (uint16_t)pos[g];  // (beyond the batch: garbage that lands behind the tile's part of lpos16)
-          lsym[i < nb ? pos[g] : TS_TILE + lane] = (uint8_t)sy[g];
+          kb[i] = (uint16_t)pos[g];
+          if (!PLACE) lsym[i < nb ? pos[g] : TS_TILE + lane] = (uint8_t)(key[g] >> 8);
         }
       }
 #ifdef FQGPU_EXPERIMENTS
       if (lane == 0) atomicAdd(&g_ts_prof[PS + 4], wall_clock64() - tr0);
 #endif
-    } else {
-      if (j + 1 < nbatch) deposit(j + 1);  // requested one batch ago
+    } else if (wave != 0) {
+      if (j >= 1 && !combine) finish(j - 1);         // ranked in the period before
+      if (j >= 1 && j + 1 < nbatch) deposit(j + 1);  // requested one period ago, into the buffer finish() has just emptied
+      if (j == 0 && nbatch > 1) deposit(1);
       if (j + 2 < nbatch) request(j + 2);
     }
     lds_barrier();
@@ -452,23 +502,30 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
   unsigned long long cursor = s_base;  // bit offset of the next sub-tile (uniform)
   // ---- packing, TS_SUB symbols per round: thread t owns 16 consecutive symbols
   // (the positions of the next round are requested before the current one is packed)
-  const uint4 *lp4 = reinterpret_cast<const uint4 *>(lpos16 + e0 + tid * PACK_PER_THREAD);
-  uint4 na = tid * PACK_PER_THREAD < nt ? lp4[0] : make_uint4(0, 0, 0, 0), nb4 = tid * PACK_PER_THREAD < nt ? lp4[1] : make_uint4(0, 0, 0, 0);
+  constexpr unsigned PPT = TS_GP_PPT, Q4 = PPT / 8;  // 16-byte pieces of positions per thread and round
+  const uint4 *lp4 = reinterpret_cast<const uint4 *>(lpos16 + e0 + tid * PPT);
+  uint4 nx[Q4];
+#pragma unroll
+  for (unsigned q = 0; q < Q4; q++) nx[q] = tid * PPT < nt ? lp4[q] : make_uint4(0, 0, 0, 0);
   for (unsigned s0 = 0; s0 < nt; s0 += TS_SUB) {
     for (unsigned i = tid; i < NW; i += TS_GP_THREADS) words[i] = 0;
-    const unsigned el = s0 + tid * PACK_PER_THREAD;  // local encode index of the thread's first symbol
-    unsigned v[PACK_PER_THREAD];
+    const unsigned el = s0 + tid * PPT;  // local encode index of the thread's first symbol
+    unsigned v[PPT];
     unsigned tb = 0;
     {
-      const uint4 a = na, b = nb4;
+      uint4 cur4[Q4];
+#pragma unroll
+      for (unsigned q = 0; q < Q4; q++) cur4[q] = nx[q];
       if (el + TS_SUB < nt) {
         const uint4 *n4 = lp4 + (s0 + TS_SUB) / 8;
-        na = n4[0]; nb4 = n4[1];
-      }
-      const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-      for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
-        const unsigned lp = (w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        for (unsigned q = 0; q < Q4; q++) nx[q] = n4[q];
+      }
+#pragma unroll
+      for (unsigned i = 0; i < PPT; i++) {
+        const uint4 c4 = cur4[i >> 3];
+        const unsigned w2 = ((i >> 1) & 3u) == 0 ? c4.x : ((i >> 1) & 3u) == 1 ? c4.y : ((i >> 1) & 3u) == 2 ? c4.z : c4.w;
+        const unsigned lp = (w2 >> (16 * (i & 1))) & 0xFFFFu;
         v[i] = el + i < nt ? (unsigned)vals[lp] : 0u;
         tb += v[i] >> 12;
       }
@@ -480,7 +537,7 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
     unsigned long long acc = 0;
     unsigned nacc = off & 31u, w = off >> 5;
 #pragma unroll
-    for (unsigned i = 0; i < PACK_PER_THREAD; i++) {
+    for (unsigned i = 0; i < PPT; i++) {
       const unsigned nb = v[i] >> 12;
       acc |= (unsigned long long)(v[i] & 0xFFFu) << nacc;
       nacc += nb;
