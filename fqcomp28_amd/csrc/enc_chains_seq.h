@@ -193,6 +193,21 @@ __device__ __forceinline__ uint4 sets_pack_rows(const uint4 cur, unsigned log) {
   return make_uint4(pk(cur.x), pk(cur.y), pk(cur.z), pk(cur.w));
 }
 
+// One gather of the two-symbol walk, table at LDS address 0 (k_seq_setfunc has no static LDS: tests/test_build_invariants.py):
+// the row offset is one 16-bit half of a scalar register (two rows per register, sets_pack_rows) and is picked by the ADD
+// itself (SDWA word select on the scalar operand), the LDS address is the sum -- add, read, wait: three instructions per
+// gather where the compiler's version had five (s_and / s_lshr for the half, s_add for the table's base).
+typedef __attribute__((address_space(3))) const uint16_t fq_lds_u16;
+template <int HALF>
+__device__ __forceinline__ unsigned sets_gather2(unsigned rowpair, unsigned y) {
+  unsigned addr;
+  if (HALF == 0)
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "s"(rowpair), "v"(y));
+  else
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "s"(rowpair), "v"(y));
+  return *reinterpret_cast<fq_lds_u16 *>((uintptr_t)addr);
+}
+
 // n classes (states in L.list) walked through words [w0, w1) of the segment, M per lane
 template <int M, bool TWO, class LT>
 __device__ __forceinline__ void sets_walk(LT &L, unsigned n, const char *tbase, unsigned log,
@@ -213,6 +228,7 @@ __device__ __forceinline__ void sets_walk(LT &L, unsigned n, const char *tbase, 
       for (int j = 0; j < M; j++) y[j] = *reinterpret_cast<const uint16_t *>(tbase + (row[i] + y[j]));
     }
   };
+  w0 = fq_uniform(w0); w1 = fq_uniform(w1);  // (wave-uniform by construction; said so, the loops below run on scalar counters)
   if ((w0 | w1) & 3u) {  // only the first two ranges of a segment: [0, 1) and [1, 4)
     for (unsigned w = w0; w < w1; w++) step_word(sets_word(cur, w));
   } else if (TWO) {  // whole groups of 16 symbols = eight prepared row offsets of lane g
@@ -221,10 +237,11 @@ __device__ __forceinline__ void sets_walk(LT &L, unsigned n, const char *tbase, 
       const unsigned r[4] = {(unsigned)__builtin_amdgcn_readlane(rows.x, gi), (unsigned)__builtin_amdgcn_readlane(rows.y, gi),
                              (unsigned)__builtin_amdgcn_readlane(rows.z, gi), (unsigned)__builtin_amdgcn_readlane(rows.w, gi)};
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const unsigned row = (i & 1) ? r[i >> 1] >> 16 : r[i >> 1] & 0xFFFFu;
+      for (int i = 0; i < 4; i++) {
 #pragma unroll
-        for (int j = 0; j < M; j++) y[j] = *reinterpret_cast<const uint16_t *>(tbase + (row + y[j]));
+        for (int j = 0; j < M; j++) y[j] = sets_gather2<0>(r[i], y[j]);
+#pragma unroll
+        for (int j = 0; j < M; j++) y[j] = sets_gather2<1>(r[i], y[j]);
       }
     }
   } else {
@@ -291,12 +308,15 @@ k_seq_setfunc(const uint8_t *__restrict__ sorted_sym, const uint32_t *__restrict
               const uint32_t *__restrict__ plan, const uint32_t *__restrict__ logs,
               const uint16_t *__restrict__ next, unsigned next_stride, const uint16_t *__restrict__ pow, unsigned pow_stride,
               unsigned S, unsigned qmax, unsigned gmin,
-              unsigned rounds, unsigned fstride, uint16_t *__restrict__ fbuf, unsigned *__restrict__ work_counter) {
+              unsigned rounds, unsigned fstride, uint16_t *__restrict__ fbuf, unsigned *__restrict__ work_counter, unsigned table_bytes) {
   constexpr unsigned WAVES = TWO ? SETS_WAVES2 : SETS_WAVES;
-  extern __shared__ uint32_t lds[];  // next[4][size] (TWO: next2[16][size]) of this context
+  // ALL of the kernel's LDS is the dynamic block, the context's table first: next[4][size] (TWO: next2[16][size]) sits at LDS
+  // address 0, so a gather's address is row + state with nothing added (with the per-wave buffers as static LDS in front of
+  // it the compiler spent one s_add per gather on the table's base); behind it the waves' set buffers and two words
   using LT = typename std::conditional<TWO, SetsWaveLds11, SetsWaveLds>::type;
-  __shared__ LT wl[WAVES];
-  __shared__ unsigned s_next, s_item;
+  extern __shared__ uint32_t lds[];
+  LT *wl = reinterpret_cast<LT *>(reinterpret_cast<char *>(lds) + table_bytes);
+  unsigned &s_next = *reinterpret_cast<unsigned *>(wl + WAVES), &s_item = *(reinterpret_cast<unsigned *>(wl + WAVES) + 1);
   constexpr unsigned B = SeqModel::B;
   const uint32_t *fitem = plan, *fseg = plan + (B + 1);
   const unsigned wave = threadIdx.x >> 6, lane = fq_lane();

@@ -286,16 +286,25 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     if (!dbg_off) hipLaunchKernelGGL(k_seq_segplan, dim3(1), dim3(256), 0, st, arrays, seq_S, Q, gmin, wpg * rounds, plan);
     FQ_SPAN_END();
     FQ_SPAN_BEGIN("seq.setfunc");
+    {  // all of k_seq_setfunc's LDS is dynamic (118 KB with the two-symbol table): say so once per process
+      static const bool raised = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seq_setfunc<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seq_setfunc<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        return true;
+      }();
+      (void)raised;
+    }
     if (!dbg_skip) {
       if (dbg_off || fq_debug_skipk("setfunc")) {
       } else if (two)
         hipLaunchKernelGGL((k_seq_setfunc<32, true>), dim3(min(max_fitems, ctx->setfunc_wgs ? ctx->setfunc_wgs : ctx->n_cus)), dim3(SETS_WAVES2 * 64),
-                           32u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2,
-                           4 * next_stride, pow, next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 5 * (B + 1));
+                           (32u << tab.max_log) + SETS_WAVES2 * sizeof(SetsWaveLds11) + 16, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next2,
+                           4 * next_stride, pow, next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 5 * (B + 1), 32u << tab.max_log);
       else
         hipLaunchKernelGGL((k_seq_setfunc<64, false>), dim3(min(max_fitems, 2 * ctx->n_cus)), dim3(SETS_WAVES * 64),
-                           8u << tab.max_log, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1,
-                           next_stride, pow, next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 5 * (B + 1));
+                           (8u << tab.max_log) + SETS_WAVES * sizeof(SetsWaveLds) + 16, st, sc.sorted_sym.as<uint8_t>(), arrays, plan, tab.logs, tab.next1,
+                           next_stride, pow, next_stride, seq_S, Q, gmin, rounds, seq_fstride, fbuf, plan + 5 * (B + 1), 8u << tab.max_log);
       FQ_SPAN_END();
       FQ_SPAN_BEGIN("seq.resolve");  dbg_off = (dbg_mask & 8u) != 0 || fq_debug_skipk("resolve");
       if (!dbg_off) {

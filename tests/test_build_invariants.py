@@ -116,3 +116,22 @@ def test_product_library_has_no_experiment_switches():
     data = open(lib, "rb").read()
     assert b"FQGPU_DEBUG" not in data
     assert b"FQ_EXP_" not in data and b"FQ_FARM_TRACE" not in data
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_seq_setfunc_table_sits_at_lds_address_zero(tmp_path):
+    """k_seq_setfunc's gathers form their LDS address as row + state with NOTHING added for the table's base
+    (sets_gather2 in enc_chains_seq.h: one SDWA add, one ds_read): right only while the context's table is the first
+    thing in the kernel's LDS, i.e. while the kernel declares no static __shared__ at all (dynamic LDS starts at 0)."""
+    out = tmp_path / "encode.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    "-I" + os.path.join(ROOT, "include"), "-o", str(out), os.path.join(ROOT, "fqcomp28_amd", "csrc", "encode.hip")],
+                   check=True, capture_output=True, timeout=900)
+    text = out.read_text()
+    kernels = re.findall(r"\.amdhsa_kernel (\S*k_seq_setfunc\S*)\n\s*\.amdhsa_group_segment_fixed_size (\d+)", text)
+    assert len(kernels) == 2, kernels
+    assert all(int(size) == 0 for _, size in kernels), kernels
+    body = text[text.index("k_seq_setfuncILj32ELb1E"):]
+    body = body[:body.index("s_endpgm")]
+    n_sdwa = len(re.findall(r"v_add_u32_sdwa v\d+, s\d+, v\d+ .*src0_sel:WORD_[01]", body))
+    assert n_sdwa >= 16, n_sdwa
