@@ -118,16 +118,34 @@ template <class M>
 __global__ void __launch_bounds__(256)
 k_epilogue(const uint32_t *__restrict__ arrays, const uint16_t *__restrict__ final_state,
            const uint32_t *__restrict__ logs, const uint32_t *__restrict__ log_prefix,
-           uint32_t *__restrict__ out, const StreamResult *res) {
+           uint32_t *__restrict__ out, const StreamResult *res, const uint4 *__restrict__ edges, unsigned n_tiles) {
   constexpr unsigned B = M::B;
   constexpr unsigned NW = (B * 12 + 1 + 31) / 32 + 2;
   __shared__ uint32_t words[NW];
   if (res->overflow) return;
+  const unsigned long long p0 = res->total_bits;
+  const unsigned sh = (unsigned)(p0 & 31ull);
+  // Tile-sorted path (edges != nullptr): the stream was never zeroed.  The words two tiles share -- or the last tile and
+  // the state flush -- were left out by k_tile_gather_pack; every tile's share of them is in edges[].  Zero each of them
+  // once, then OR the shares in (one workgroup: the two passes are separated by its barrier).
+  if (edges != nullptr) {
+    for (unsigned t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+      const uint4 e = edges[t];
+      if (e.x != 0xFFFFFFFFu) out[e.x] = 0u;
+      if (e.z != 0xFFFFFFFFu) out[e.z] = 0u;
+    }
+    if (threadIdx.x == 0 && sh == 0u) out[p0 >> 5] = 0u;  // (the flush starts a word of its own: nobody has listed it)
+    __threadfence();
+    __syncthreads();
+    for (unsigned t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+      const uint4 e = edges[t];
+      if (e.x != 0xFFFFFFFFu && e.y) atomicOr(&out[e.x], e.y);
+      if (e.z != 0xFFFFFFFFu && e.w) atomicOr(&out[e.z], e.w);
+    }
+  }
   const uint32_t *ctx_count = arrays;
   for (unsigned i = threadIdx.x; i < NW; i += blockDim.x) words[i] = 0;
   __syncthreads();
-  const unsigned long long p0 = res->total_bits;
-  const unsigned sh = (unsigned)(p0 & 31ull);
   for (unsigned c = threadIdx.x; c <= B; c += blockDim.x) {
     unsigned val, nb;
     if (c < B) {

@@ -9,7 +9,8 @@ struct __attribute__((packed)) FqBytes16 { uint32_t w[4]; };  // 16 bytes at any
 __global__ void __launch_bounds__(256)
 k_readlens_ncount(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R,
                   uint16_t *__restrict__ readlens, uint16_t *__restrict__ n_count,
-                  uint32_t *__restrict__ n_cnt32, uint32_t *__restrict__ lens32) {
+                  uint32_t *__restrict__ n_cnt32, uint32_t *__restrict__ lens32, BlockResult *res) {
+  if (res != nullptr && blockIdx.x == 0 && threadIdx.x < sizeof(BlockResult) / 4) reinterpret_cast<uint32_t *>(res)[threadIdx.x] = 0u;  // the block's result starts clean (first kernel of the encode: no memset in front of it)
   const unsigned waves = (gridDim.x * blockDim.x) >> 6;
   const unsigned lane = fq_lane(), sub = lane >> 4, l = lane & 15u;
   for (unsigned r0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4; r0 < R; r0 += waves * 4) {
@@ -41,7 +42,8 @@ k_readlens_ncount(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__
 // counted by K1 (k_tile_hist2), which sees every base anyway, into n_cnt32 -- zeroed here.
 __global__ void __launch_bounds__(256)
 k_readlens(const fqgpu_rec *__restrict__ recs, unsigned R, uint16_t *__restrict__ readlens,
-           uint32_t *__restrict__ n_cnt32, uint32_t *__restrict__ lens32) {
+           uint32_t *__restrict__ n_cnt32, uint32_t *__restrict__ lens32, BlockResult *res) {
+  if (res != nullptr && blockIdx.x == 0 && threadIdx.x < sizeof(BlockResult) / 4) reinterpret_cast<uint32_t *>(res)[threadIdx.x] = 0u;  // the block's result starts clean (first kernel of the encode: no memset in front of it)
   for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
     const unsigned len = recs[r].len;
     readlens[r] = (uint16_t)len;
@@ -163,11 +165,12 @@ __device__ __forceinline__ unsigned sets_incl_scan_k1(unsigned v) {  // inclusiv
 // prefetchable linear scan: ckey[e] = ctx | sym << 8 (sequence: 10 bits) or ctx (quality: 13
 // bits, the symbol goes to csym[e]).  Two or three bytes per symbol instead of four: the key
 // stores alone were 2.7 of the 21 ms step (tools/traffic_experiment.py).
-template <class M>
+// HT: type of a histogram row's entries -- uint16_t on the tile-sorted path (a tile has at most 32768 symbols), else uint32_t
+template <class M, class HT>
 __global__ void __launch_bounds__(256)
 k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
             const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
-            uint32_t *__restrict__ tile_hist, uint16_t *__restrict__ ckey, uint8_t *__restrict__ csym,
+            HT *__restrict__ tile_hist, uint16_t *__restrict__ ckey, uint8_t *__restrict__ csym,
             StreamResult *res, int dbg) {
   // Quality stream: 16-bit counters, two per word -- 16 KB of LDS instead of 32, so that a CU takes
   // seven of these workgroups, or four and still has room for another kernel's.  A tile has up to
@@ -270,10 +273,10 @@ k_tile_hist(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
     const unsigned c0 = s_first_ctx;
     const bool wrapped = e1 > e0 && ((hist[c0 >> 1] >> (16u * (c0 & 1u))) & 0xFFFFu) == 0u;  // 65536 symbols, all in c0
     for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x)
-      tile_hist[(size_t)tile * M::B + c] = wrapped ? (c == c0 ? e1 - e0 : 0u) : (hist[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu;
+      tile_hist[(size_t)tile * M::B + c] = (HT)(wrapped ? (c == c0 ? e1 - e0 : 0u) : (hist[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu);
   } else {
     for (unsigned c = threadIdx.x; c < (unsigned)M::B; c += blockDim.x)
-      tile_hist[(size_t)tile * M::B + c] = hist[c];
+      tile_hist[(size_t)tile * M::B + c] = (HT)hist[c];
   }
 }
 
@@ -311,8 +314,8 @@ constexpr int K1Q_DEPTH = FQ_K1Q_DEPTH;  // quad chunks (256 symbols) whose wind
 __global__ void __launch_bounds__(256)
 k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
              const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
-             uint32_t *__restrict__ tile_hist_seq, uint16_t *__restrict__ ckey_seq,
-             uint32_t *__restrict__ tile_hist_qual, uint16_t *__restrict__ ckey_qual, uint8_t *__restrict__ csym_qual,
+             uint16_t *__restrict__ tile_hist_seq, uint16_t *__restrict__ ckey_seq,
+             uint16_t *__restrict__ tile_hist_qual, uint16_t *__restrict__ ckey_qual, uint8_t *__restrict__ csym_qual,
              uint32_t *__restrict__ n_cnt32, BlockResult *res) {
   constexpr unsigned BS = SeqModel::B, BQ = QualModel::B;
   __shared__ uint32_t hist_s[BS];
@@ -481,15 +484,18 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
   if (bad_s) atomicOr(&res->s[0].bad_symbol, 1u);
   if (bad_q) atomicOr(&res->s[1].bad_symbol, 1u);
   __syncthreads();
-  for (unsigned c = threadIdx.x; c < BS; c += blockDim.x) tile_hist_seq[(size_t)tile * BS + c] = hist_s[c];
-  for (unsigned c = threadIdx.x; c < BQ; c += blockDim.x)
-    tile_hist_qual[(size_t)tile * BQ + c] = (hist_q[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu;
+  // histogram rows as 16-bit entries (a tile has at most 32768 symbols): the quality stream's rows are 3662 x 8192 entries
+  // per 256 MiB block -- 60 MB written here and read twice by K2 and once by K3 instead of 120; the packed LDS words go out as they are
+  for (unsigned c = threadIdx.x; c < BS; c += blockDim.x) tile_hist_seq[(size_t)tile * BS + c] = (uint16_t)hist_s[c];
+  uint32_t *rowq = reinterpret_cast<uint32_t *>(tile_hist_qual + (size_t)tile * BQ);
+  for (unsigned c = threadIdx.x; c < BQ / 2; c += blockDim.x) rowq[c] = hist_q[c];
 }
 
 // ------------------------------------------------------------------ K2: layout of the sorted arrays
 // group_sum[g][c] = sum of tile_hist over the tiles of group g
+template <class HT>
 __global__ void __launch_bounds__(256)
-k_group_sum(const uint32_t *__restrict__ tile_hist, unsigned n_tiles, unsigned B,
+k_group_sum(const HT *__restrict__ tile_hist, unsigned n_tiles, unsigned B,
             uint32_t *__restrict__ group_sum) {
   const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned g = blockIdx.y;
@@ -565,8 +571,9 @@ k_ctx_layout(unsigned B, unsigned S, uint32_t *__restrict__ arrays, uint32_t *__
 }
 
 // tile_base[t][c] = ctx_start[c] + (symbols of context c in tiles before t)
+template <class HT>
 __global__ void __launch_bounds__(256)
-k_tile_base(const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ group_sum,
+k_tile_base(const HT *__restrict__ tile_hist, const uint32_t *__restrict__ group_sum,
             const uint32_t *__restrict__ ctx_start, unsigned n_tiles, unsigned B,
             uint32_t *__restrict__ tile_base) {
   const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -104,11 +104,17 @@ __device__ __forceinline__ void ts_clear_bitmap(TsRunMap &m) {
 template <class M>
 __global__ void __launch_bounds__(TS_THREADS)
 k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ csym, unsigned n_sym,
-                 const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ tile_base,
+                 const uint16_t *__restrict__ tile_hist, const uint32_t *__restrict__ tile_base,
                  uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ lpos16, uint2 *__restrict__ runs,
-                 uint32_t *__restrict__ run_count) {
+                 uint32_t *__restrict__ run_count, unsigned long long *__restrict__ k6_status, unsigned *__restrict__ k6_counter) {
   constexpr unsigned B = M::B;
   constexpr bool QUAL = M::STREAM == 1;
+  // K6's look-back starts from clean words: this kernel runs in front of it on the same stream and has a workgroup per tile
+  // (a memset per stream and block less)
+  if (k6_status != nullptr && threadIdx.x == 0) {
+    k6_status[blockIdx.x] = 0ull;
+    if (blockIdx.x == 0) *k6_counter = 0u;
+  }
   constexpr unsigned NCHUNK = B / 64;  // 64 contexts per chunk: 128 (quality) / 4 (sequence)
   __shared__ uint32_t cursor32[B / 2];  // 16-bit cursors (local positions), two per word
   __shared__ __attribute__((aligned(16))) uint8_t lsym[TS_TILE + 64];  // the tile's symbols in sorted order (+ a dump for idle lanes)
@@ -138,7 +144,8 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   uint16_t *cur16 = reinterpret_cast<uint16_t *>(cursor32);
   const unsigned tile = fq_xcd_tile(blockIdx.x, gridDim.x), tid = threadIdx.x, wave = tid >> 6, lane = fq_lane();
   const unsigned e0 = tile * TS_TILE, nt = min(TS_TILE, n_sym - e0);
-  const uint32_t *hrow = tile_hist + (size_t)tile * B, *tb_row = tile_base + (size_t)tile * B;
+  const uint16_t *hrow = tile_hist + (size_t)tile * B;
+  const uint32_t *tb_row = tile_base + (size_t)tile * B;
   TS_PROF_DECL
   constexpr unsigned PS = QUAL ? 0 : 8; (void)PS;
 
@@ -405,7 +412,7 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
                    const uint32_t *__restrict__ run_count, const uint16_t *__restrict__ out16, unsigned n_sym,
                    unsigned n_tiles, unsigned long long *__restrict__ status, unsigned *__restrict__ tile_counter,
                    const uint32_t *__restrict__ log_prefix, unsigned long long cap, uint32_t *__restrict__ out,
-                   StreamResult *res, unsigned long long *__restrict__ tile_bit_base) {
+                   StreamResult *res, unsigned long long *__restrict__ tile_bit_base, uint4 *__restrict__ edges) {
   constexpr unsigned NW = TS_SUB * 12 / 32 + 4;
   __shared__ uint16_t vals[TS_TILE];  // (nb, bits) of the tile in sorted order
   __shared__ uint32_t words[NW];
@@ -413,7 +420,10 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
   __shared__ unsigned wsum[TS_GP_THREADS / 64], s_tile;
   __shared__ unsigned long long s_base;
   const unsigned tid = threadIdx.x, wave = tid >> 6, lane = fq_lane();
-  if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+  if (tid == 0) {
+    s_tile = atomicAdd(tile_counter, 1u);
+    if (s_tile < n_tiles) edges[s_tile] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);  // no shared words yet
+  }
   ts_clear_bitmap<TS_GP_THREADS>(rm);
   __syncthreads();
   const unsigned tile = s_tile;
@@ -500,6 +510,14 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
   __syncthreads();
   TS_PROF(PS + 2);
   unsigned long long cursor = s_base;  // bit offset of the next sub-tile (uniform)
+  // Nobody zeroes the stream (round 3: a memset of its whole capacity per stream and block, 138 MB).  A word that this
+  // tile alone fills is stored; a word it shares -- with the tile in front (its first word, when the tile does not start
+  // on a word boundary), with the tile or the state flush behind (its last word) -- is NOT written here: the tile's share
+  // of it goes to edges[tile] = {first word's index, bits, last word's index, bits}, and k_epilogue, which runs behind this
+  // kernel, zeroes every such word once and ORs the shares in.  Between two rounds of one tile the open word travels in `carry`.
+  const unsigned first_word = (unsigned)(s_base >> 5);
+  const bool first_shared = (s_base & 31ull) != 0;
+  unsigned carry = 0;  // (uniform) this tile's bits in the word that holds bit `cursor`, when cursor is not on a word boundary
   // ---- packing, TS_SUB symbols per round: thread t owns 16 consecutive symbols
   // (the positions of the next round are requested before the current one is packed)
   constexpr unsigned PPT = TS_GP_PPT, Q4 = PPT / 8;  // 16-byte pieces of positions per thread and round
@@ -508,7 +526,7 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
 #pragma unroll
   for (unsigned q = 0; q < Q4; q++) nx[q] = tid * PPT < nt ? lp4[q] : make_uint4(0, 0, 0, 0);
   for (unsigned s0 = 0; s0 < nt; s0 += TS_SUB) {
-    for (unsigned i = tid; i < NW; i += TS_GP_THREADS) words[i] = 0;
+    for (unsigned i = tid; i < NW; i += TS_GP_THREADS) words[i] = i == 0 ? carry : 0u;
     const unsigned el = s0 + tid * PPT;  // local encode index of the thread's first symbol
     unsigned v[PPT];
     unsigned tb = 0;
@@ -548,21 +566,29 @@ k_tile_gather_pack(const uint16_t *__restrict__ lpos16, const uint2 *__restrict_
     }
     if ((uint32_t)acc) atomicOr(&words[w], (uint32_t)acc);
     __syncthreads();
-    if (b1 != b0) {
+    {
       const unsigned long long gw0 = b0 >> 5;
-      const unsigned nw = (unsigned)(((b1 + 31ull) >> 5) - gw0);
-      // the stream was zeroed before the launch: words shared with a neighbour are OR-ed
+      const unsigned nw = (unsigned)(((b1 + 31ull) >> 5) - gw0);   // words that hold bits of this tile up to b1 (word 0: the carry's)
+      const bool tail_open = (b1 & 31ull) != 0;
+      const unsigned n_final = tail_open ? nw - 1u : nw;           // ... and are complete as far as this tile goes
       const bool fits = (gw0 + nw) * 4ull <= cap + 32ull;  // (the buffer has 64 spare bytes; an overflowing stream is discarded)
-      const bool tail_shared = (b1 & 31ull) != 0;
-      if (fits)
-        for (unsigned i = tid; i < nw; i += TS_GP_THREADS) {
-          if (i == 0 || (tail_shared && i == nw - 1)) atomicOr(&out[gw0 + i], words[i]);
-          else out[gw0 + i] = words[i];
+      const unsigned next_carry = tail_open ? words[nw - 1u] : 0u;
+      if (fits) {
+        for (unsigned i = tid; i < n_final; i += TS_GP_THREADS) {
+          const unsigned gw = (unsigned)gw0 + i;
+          if (gw == first_word && first_shared) { edges[tile].x = gw; edges[tile].y = words[i]; }  // (one thread, once per tile)
+          else out[gw] = words[i];
         }
-      else if (tid == 0) atomicOr(&res->overflow, 1u);
+      } else if (tid == 0) atomicOr(&res->overflow, 1u);
+      carry = next_carry;
     }
     cursor = b1;
     __syncthreads();  // words are rewritten by the next round
+  }
+  if (tid == 0 && (cursor & 31ull) != 0 && (cursor >> 5) * 4ull + 4ull <= cap + 32ull) {  // the open last word: shared with whatever follows
+    const unsigned gw = (unsigned)(cursor >> 5);
+    if (gw == first_word && first_shared) { edges[tile].x = gw; edges[tile].y = carry; }  // the whole tile inside one word
+    else { edges[tile].z = gw; edges[tile].w = carry; }
   }
   TS_PROF(PS + 3);
 }

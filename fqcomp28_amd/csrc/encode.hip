@@ -198,10 +198,12 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   if (serial_seq && (rc = sc.seq_bdesc.reserve((size_t)(n_ptiles + 1) * SeqModel::B * 6 + 64))) return rc;
   if ((rc = sc.tile_bits.reserve((size_t)n_ptiles * 4))) return rc;
   if ((rc = sc.tile_bit_base.reserve((size_t)(n_ptiles + 1) * 8))) return rc;
+  // tile_sync: K6's look-back status u64 [tiles] | ticket counter, pad | run counts u32 [tiles] (16-byte aligned) | edge words uint4 [tiles]
   const size_t sync_counter_off = (size_t)n_tiles * 8, sync_runcount_off = sync_counter_off + 16;
+  const size_t sync_edges_off = (sync_runcount_off + (size_t)n_tiles * 4 + 15) & ~(size_t)15;
   if (tile_path) {
     if ((rc = sc.tile_runs.reserve((size_t)n_tiles * ts_run_stride<M>() * sizeof(uint2)))) return rc;
-    if ((rc = sc.tile_sync.reserve(sync_runcount_off + (size_t)n_tiles * 4))) return rc;
+    if ((rc = sc.tile_sync.reserve(sync_edges_off + (size_t)n_tiles * 16))) return rc;
   }
 
   if (reserve_only) return FQGPU_OK;  // (fqgpu_ctx_reserve: the scratch of a block of this shape exists now)
@@ -221,19 +223,29 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   (void)pfx;
 
   FQ_SPAN_BEGIN(M::STREAM ? "qual.tile_hist" : "seq.tile_hist");  dbg_off = (dbg_mask & 1u) != 0 || fused_k1(ctx);
-  if (!dbg_off) hipLaunchKernelGGL(k_tile_hist<M>, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs,
-                     rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), ckey, csym, res,
-                     fq_debug_k1());
+  if (!dbg_off) {
+    if (tile_path) hipLaunchKernelGGL((k_tile_hist<M, uint16_t>), dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs,
+                                      rec_start, R, n_sym, T, sc.tile_hist.as<uint16_t>(), ckey, csym, res, fq_debug_k1());
+    else hipLaunchKernelGGL((k_tile_hist<M, uint32_t>), dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs,
+                            rec_start, R, n_sym, T, sc.tile_hist.as<uint32_t>(), ckey, csym, res, fq_debug_k1());
+  }
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.layout" : "seq.layout");  dbg_off = (dbg_mask & 2u) != 0 || fq_debug_skipk(M::STREAM ? "k2q" : "k2s");
-  if (!dbg_off) hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
-                     sc.tile_hist.as<uint32_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
+  if (!dbg_off) {
+    if (tile_path) hipLaunchKernelGGL(k_group_sum<uint16_t>, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
+                                      sc.tile_hist.as<uint16_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
+    else hipLaunchKernelGGL(k_group_sum<uint32_t>, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
+                            sc.tile_hist.as<uint32_t>(), n_tiles, B, sc.group_sum.as<uint32_t>());
+  }
   if (!dbg_off) hipLaunchKernelGGL(k_group_prefix, dim3((B + 255) / 256), dim3(256), 0, st, sc.group_sum.as<uint32_t>(), n_groups, B, arrays);
   if (!dbg_off) hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, B, S, arrays,
                      serial_seq ? nullptr : reinterpret_cast<uint32_t *>(sc.seg_arrays.as<uint8_t>() + sa_usym));
-  if (!dbg_off) hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
-                     sc.tile_hist.as<uint32_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B,
-                     sc.tile_base.as<uint32_t>());
+  if (!dbg_off) {
+    if (tile_path) hipLaunchKernelGGL(k_tile_base<uint16_t>, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
+                                      sc.tile_hist.as<uint16_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B, sc.tile_base.as<uint32_t>());
+    else hipLaunchKernelGGL(k_tile_base<uint32_t>, dim3((B + 255) / 256, n_groups), dim3(256), 0, st,
+                            sc.tile_hist.as<uint32_t>(), sc.group_sum.as<uint32_t>(), arrays + B, n_tiles, B, sc.tile_base.as<uint32_t>());
+  }
   FQ_SPAN_END();
   FQ_SPAN_BEGIN(M::STREAM ? "qual.scatter" : "seq.scatter");  dbg_off = (dbg_mask & 4u) != 0 || fq_debug_skipk(M::STREAM ? "k3q" : "k3s");
   SeqBatchDesc bd;
@@ -244,10 +256,11 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   unsigned long long *ts_status = reinterpret_cast<unsigned long long *>(sync_base);
   unsigned *ts_counter = reinterpret_cast<unsigned *>(sync_base + sync_counter_off);
   uint32_t *ts_run_count = reinterpret_cast<uint32_t *>(sync_base + sync_runcount_off);
+  uint4 *ts_edges = reinterpret_cast<uint4 *>(sync_base + sync_edges_off);
   if (tile_path) {
     if (!dbg_off)
-      hipLaunchKernelGGL(k_tile_partition<M>, dim3(n_tiles), dim3(TS_THREADS), 0, st, ckey, csym, n_sym, sc.tile_hist.as<uint32_t>(),
-                         sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), lpos16, sc.tile_runs.as<uint2>(), ts_run_count);
+      hipLaunchKernelGGL(k_tile_partition<M>, dim3(n_tiles), dim3(TS_THREADS), 0, st, ckey, csym, n_sym, sc.tile_hist.as<uint16_t>(),
+                         sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), lpos16, sc.tile_runs.as<uint2>(), ts_run_count, ts_status, ts_counter);
   } else if (!dbg_off && serial_seq) {
     if (ctx->lds_atomics_ordered)
       hipLaunchKernelGGL(k_scatter_seq<true>, dim3(n_tiles), dim3(64), 0, st, ckey, n_sym, T, sc.tile_base.as<uint32_t>(),
@@ -371,11 +384,9 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
     // the stream starts from zeros (words shared by two tiles are OR-ed into), the look-back from clean flags
     FQ_SPAN_BEGIN(M::STREAM ? "qual.gatherpack" : "seq.gatherpack");  dbg_off = (dbg_mask & 16u) != 0 || fq_debug_skipk(M::STREAM ? "k6q" : "k6s");
     if (!dbg_off) {
-      FQ_HIP(hipMemsetAsync(out_dev, 0, cap + 64, st));
-      FQ_HIP(hipMemsetAsync(sync_base, 0, sync_counter_off + 16, st));
       hipLaunchKernelGGL(k_tile_gather_pack<M>, dim3(n_tiles), dim3(TS_GP_THREADS), 0, st, lpos16, sc.tile_runs.as<uint2>(), ts_run_count,
                          sc.out16.as<uint16_t>(), n_sym, n_tiles, ts_status, ts_counter, tab.log_prefix, (unsigned long long)cap,
-                         reinterpret_cast<uint32_t *>(out_dev), res, sc.tile_bit_base.as<unsigned long long>());
+                         reinterpret_cast<uint32_t *>(out_dev), res, sc.tile_bit_base.as<unsigned long long>(), ts_edges);
     }
     FQ_SPAN_END();
   } else {
@@ -399,7 +410,7 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   }
   FQ_SPAN_BEGIN(M::STREAM ? "qual.epilogue" : "seq.epilogue");  dbg_off = (dbg_mask & 128u) != 0;
   if (!dbg_off) hipLaunchKernelGGL(k_epilogue<M>, dim3(1), dim3(256), 0, st, arrays, final_state, tab.logs,
-                     tab.log_prefix, reinterpret_cast<uint32_t *>(out_dev), res);
+                     tab.log_prefix, reinterpret_cast<uint32_t *>(out_dev), res, tile_path ? ts_edges : (const uint4 *)nullptr, n_tiles);
   FQ_SPAN_END();
   b->index_bytes[M::STREAM] = 0;
   if ((flags & FQGPU_F_DECODE_INDEX) && !dbg_mask) {
@@ -559,20 +570,21 @@ int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_re
     uint16_t *kq = sq.keys.as<uint16_t>();
     if (hipMemsetAsync(res, 0, sizeof(BlockResult), st) != hipSuccess) { rc = FQGPU_E_HIP; break; }
     hipLaunchKernelGGL(k_readlens, dim3((unsigned)min((size_t)(R + 255) / 256, (size_t)2048)), dim3(256), 0, st, recs_dev, R,
-                       readlens.as<uint16_t>(), n_cnt32, lens32);
+                       readlens.as<uint16_t>(), n_cnt32, lens32, (BlockResult *)nullptr);
     if ((rc = fq_scan_u32_to_u32(st, lens32, R, rec_start, lane.scan_tmp))) break;
     hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, raw_dev, recs_dev, rec_start, R, n_sym, TS_TILE,
-                       ss.tile_hist.as<uint32_t>(), ss.keys.as<uint16_t>(), sq.tile_hist.as<uint32_t>(), kq,
+                       ss.tile_hist.as<uint16_t>(), ss.keys.as<uint16_t>(), sq.tile_hist.as<uint16_t>(), kq,
                        reinterpret_cast<uint8_t *>(kq + n_pad), n_cnt32, res);
-    hipLaunchKernelGGL(k_group_sum, dim3((B + 255) / 256, n_groups), dim3(256), 0, st, sq.tile_hist.as<uint32_t>(), n_tiles, B, sq.group_sum.as<uint32_t>());
+    hipLaunchKernelGGL(k_group_sum<uint16_t>, dim3((B + 255) / 256, n_groups), dim3(256), 0, st, sq.tile_hist.as<uint16_t>(), n_tiles, B, sq.group_sum.as<uint32_t>());
     hipLaunchKernelGGL(k_group_prefix, dim3((B + 255) / 256), dim3(256), 0, st, sq.group_sum.as<uint32_t>(), n_groups, B, arrays);
     hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, B, S, arrays, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_tile_base, dim3((B + 255) / 256, n_groups), dim3(256), 0, st, sq.tile_hist.as<uint32_t>(), sq.group_sum.as<uint32_t>(),
+    hipLaunchKernelGGL(k_tile_base<uint16_t>, dim3((B + 255) / 256, n_groups), dim3(256), 0, st, sq.tile_hist.as<uint16_t>(), sq.group_sum.as<uint32_t>(),
                        arrays + B, n_tiles, B, sq.tile_base.as<uint32_t>());
     // (the rank only has to be a permutation here, not a stable one: no lane-ordered atomics are relied on)
     hipLaunchKernelGGL(k_tile_partition<QualModel>, dim3(n_tiles), dim3(TS_THREADS), 0, st, kq, reinterpret_cast<uint8_t *>(kq + n_pad), n_sym,
-                       sq.tile_hist.as<uint32_t>(), sq.tile_base.as<uint32_t>(), sq.sorted_sym.as<uint8_t>(),
-                       reinterpret_cast<uint16_t *>(sq.slot_of.as<uint32_t>()), sq.tile_runs.as<uint2>(), sq.tile_sync.as<uint32_t>());
+                       sq.tile_hist.as<uint16_t>(), sq.tile_base.as<uint32_t>(), sq.sorted_sym.as<uint8_t>(),
+                       reinterpret_cast<uint16_t *>(sq.slot_of.as<uint32_t>()), sq.tile_runs.as<uint2>(), sq.tile_sync.as<uint32_t>(),
+                       (unsigned long long *)nullptr, (unsigned *)nullptr);
     hipLaunchKernelGGL(k_hist_sorted_qual, dim3((max_segs + 3) / 4), dim3(256), 0, st, sq.sorted_sym.as<uint8_t>(), arrays, S, counts_dev);
     BlockResult h;
     if (hipMemcpyAsync(&h, res, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
@@ -621,18 +633,17 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
     return encode_stream<SeqModel>(ctx, lane, lane.st_seq, b, rec_start, nullptr, 0, flags, true);
   }
 
-  FQ_HIP(hipMemsetAsync(b->result, 0, sizeof(BlockResult), st));
   const unsigned rec_blocks = (unsigned)min((size_t)(R + 3) / 4, (size_t)8192);  // k_npos: a wave per record
   const unsigned len_blocks = (unsigned)min((size_t)(R + 15) / 16, (size_t)4096);  // four records per wave
   const bool fused = fused_k1(ctx);
   FQ_SPAN_BEGIN("records");
   if (fused) {  // lengths from the record table alone; K1 counts the N's (the raw block is read once less)
     hipLaunchKernelGGL(k_readlens, dim3((unsigned)min((size_t)(R + 255) / 256, (size_t)2048)), dim3(256), 0, st, b->recs, R, b->readlens,
-                       n_cnt32, lens32);
+                       n_cnt32, lens32, b->result);
     if ((rc = fq_scan_u32_to_u32(st, lens32, R, rec_start, lane.scan_tmp))) return rc;
   } else {
     hipLaunchKernelGGL(k_readlens_ncount, dim3(len_blocks), dim3(256), 0, st, b->raw, b->recs, R,
-                       b->readlens, b->n_count, n_cnt32, lens32);
+                       b->readlens, b->n_count, n_cnt32, lens32, b->result);
     if ((rc = fq_scan2_u32_to_u32(st, lens32, n_cnt32, R, rec_start, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
     hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
   }
@@ -645,7 +656,7 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
     uint16_t *kq = lane.enc[1].keys.as<uint16_t>();
     FQ_SPAN_BEGIN("tile_hist2");
     if (!fq_debug_skipk("k1")) hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R, n_sym, TS_TILE,
-                       lane.enc[0].tile_hist.as<uint32_t>(), lane.enc[0].keys.as<uint16_t>(), lane.enc[1].tile_hist.as<uint32_t>(), kq,
+                       lane.enc[0].tile_hist.as<uint16_t>(), lane.enc[0].keys.as<uint16_t>(), lane.enc[1].tile_hist.as<uint16_t>(), kq,
                        reinterpret_cast<uint8_t *>(kq + n_pad), n_cnt32, b->result);
     FQ_SPAN_END();
   }
