@@ -139,6 +139,9 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   uint4 (*kb4)[TS_BATCH / 8] = reinterpret_cast<uint4 (*)[TS_BATCH / 8]>(stage_raw);
   uint2 (*sb8)[PLACE ? TS_BATCH / 8 : 1] = reinterpret_cast<uint2 (*)[PLACE ? TS_BATCH / 8 : 1]>(stage_raw + KB_BYTES);  // the symbols of key piece p: eight bytes
   TsRunMap &rm = *reinterpret_cast<TsRunMap *>(stage_raw);
+  // behind the run map, once the batch buffers are dead: the first GD_CAP runs' offsets "global slot - local position"
+  constexpr unsigned GD_CAP = (sizeof(stage_raw) - sizeof(TsRunMap)) / 4;
+  uint32_t *gd = reinterpret_cast<uint32_t *>(stage_raw + sizeof(TsRunMap));
   __shared__ unsigned wsum[TS_WAVES], s_cnt[NCHUNK < 2 ? 2 : NCHUNK], s_nruns, s_max;
   __shared__ uint32_t dummy[64];  // where the lanes of the combining ranker that are no run heads send their (empty) atomics
   uint16_t *cur16 = reinterpret_cast<uint16_t *>(cursor32);
@@ -380,7 +383,9 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
     if (chunk < NCHUNK && my_len[k]) {
       const unsigned c = chunk * 64 + lane;
       const unsigned slot = s_cnt[chunk] + fq_mbcnt(my_mask[k]);
-      rlist[slot] = make_uint2(tb_row[c], my_beg[k] | (my_len[k] << 16));
+      const unsigned slot_base = tb_row[c];
+      rlist[slot] = make_uint2(slot_base, my_beg[k] | (my_len[k] << 16));
+      if (slot < GD_CAP) gd[slot] = slot_base - my_beg[k];  // "global slot of local position p" = p + gd[run of p]
       atomicOr(&rm.bm[my_beg[k] >> 5], 1u << (my_beg[k] & 31u));
     }
   }
@@ -388,11 +393,35 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   ts_build_wpre<TS_THREADS>(rm, wsum);
   if (tid == 0) run_count[tile] = s_nruns;
   TS_PROF(PS + 2);
-  // position-major copy: lane p stores byte p of the sorted tile
-#pragma unroll 8
-  for (unsigned p = tid; p < nt; p += TS_THREADS) {
-    const uint2 r = rlist[ts_run_of(rm, p)];
-    sorted_sym[r.x + (p - (r.y & 0xFFFFu))] = lsym[p];
+  // The sorted tile goes out in pieces of 16 positions per thread.  A piece that lies inside ONE run -- nearly all of them
+  // for the sequence stream (runs of 128), most for the quality stream -- is one 16-byte LDS read, one run lookup and one
+  // 16-byte store (round 3: a run lookup = two LDS reads and a global read, and a byte store, per POSITION); a piece with
+  // run boundaries inside walks its bytes, stepping to the next run where the boundary map says so.  +1.3 % on the step.
+  // (The same for K6's gather of the (nb, bits) LOST 11 %: there a piece with boundaries walks sixteen dependent global
+  // loads where the position-major loop keeps sixteen independent ones in flight per thread.)
+  for (unsigned p0 = tid * 16u; p0 < nt; p0 += TS_THREADS * 16u) {
+    const unsigned wd = p0 >> 5, shb = p0 & 31u;  // (p0 is a multiple of 16: the piece is one half of a map word)
+    const unsigned mw = rm.bm[wd];
+    const unsigned starts = (mw >> shb) & 0xFFFFu;   // run starts at positions p0 .. p0 + 15
+    unsigned r = (unsigned)rm.wpre[wd] + __popc(mw & ((1u << shb) - 1u)) + (starts & 1u) - 1u;  // run of position p0
+    const uint4 v = *reinterpret_cast<const uint4 *>(lsym + p0);
+    const unsigned n = min(16u, nt - p0);
+    auto delta_of = [&](unsigned run) {
+      if (run < GD_CAP) return gd[run];
+      const uint2 e = rlist[run];
+      return e.x - (e.y & 0xFFFFu);
+    };
+    unsigned delta = delta_of(r);
+    if ((starts & 0xFFFEu) == 0u && n == 16u) {
+      *reinterpret_cast<FqBytes16 *>(sorted_sym + p0 + delta) = FqBytes16{{v.x, v.y, v.z, v.w}};  // (16 bytes at any address)
+    } else {
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (unsigned i = 0; i < 16; i++) {
+        if (i && ((starts >> i) & 1u)) { r++; delta = delta_of(r); }
+        if (i < n) sorted_sym[p0 + i + delta] = (uint8_t)(w4[i >> 2] >> (8u * (i & 3u)));
+      }
+    }
   }
   __syncthreads();
   TS_PROF(PS + 3);
