@@ -350,7 +350,7 @@ def main():
     ap.add_argument("--sample-mib", type=int, default=128, help="-S of the reference")
     ap.add_argument("--decode-block-mib", type=int, default=1, help="block size of the many-blocks decode run")
     ap.add_argument("--decode-mib", type=int, default=256, help="data decoded in the many-blocks run")
-    ap.add_argument("--lanes", type=int, default=4, help="blocks in flight per GPU (encode lanes)")
+    ap.add_argument("--lanes", type=int, default=0, help="blocks in flight per GPU (encode lanes); 0 = the library's default: four, six for blocks below 48 M symbols")
     ap.add_argument("--seq-mode", default="sets", choices=["sets", "generic"],
                     help="sequence chain kernels: segment functions over state sets (default), reset-cut kernel")
     ap.add_argument("--seq-segment", type=int, default=None, help="segment length of the sequence chain kernels")
@@ -413,7 +413,7 @@ def main():
             sft, qft = sample_tables(F, blocks, args.sample_mib << 20, device)
         job_blocks = len(blocks) * world
     ctx = F.Context(sft, qft, device=device)
-    ctx.set_lanes(max(1, min(args.lanes, 8)))
+    ctx.set_lanes(max(0, min(args.lanes, 8)))
     ctx.set_chain_params(args.segment, seq_generic=args.seq_mode == "generic", seq_segment=args.seq_segment)
     dblocks = [ctx.dblock(raw, recs) for raw, recs in blocks]
     raw_bytes = sum(raw.size for raw, _ in blocks)
@@ -549,7 +549,7 @@ def main():
     extra = {}
     # ---- BASELINE configs[2] at every N (after the timed region; all ranks): the reference's own scaling config
     if not args.skip_strong and layout != "strong":
-        sc2 = strong_config2(F, farm, dist, rank, world, device, max(1, min(args.lanes, 8)), max(3, args.steps), 1024, 64, args.sample_mib,
+        sc2 = strong_config2(F, farm, dist, rank, world, device, max(0, min(args.lanes, 8)), max(3, args.steps), 1024, 64, args.sample_mib,
                              None if args.skip_cpu else _oracle())
         extra["strong_config2_MBps"] = sc2["MBps"]
         extra["strong_config2"] = sc2
@@ -730,7 +730,7 @@ def main():
     # ---- data that is not the headline config (rank 0, after the timed region; not part of `value`)
     if rank == 0 and not args.skip_other_data:
         Oc = None if args.skip_cpu else _oracle()
-        lanes = max(1, min(args.lanes, 8))
+        lanes = max(0, min(args.lanes, 8))
         od = [other_data(F, Oc, device, lanes, 5, "binned qualities: four levels at 5/10/15/70 %, kept w.p. 0.85 (synth mode 3)", 3, 1024, 256, 128, 16),
               other_data(F, Oc, device, lanes, 5, "constant: every base A, every quality F (synth mode 5)", 5, 1024, 256, 128, 16),
               other_data(F, Oc, device, lanes, 5, "BASELINE configs[3]: 256 MiB, length U[50,300], 1 % N (synth mode 4), in -R 64 blocks", 4, 256, 64, 128, 0)]

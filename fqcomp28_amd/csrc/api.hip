@@ -275,8 +275,8 @@ extern "C" int fqgpu_ctx_last_timing(fqgpu_ctx *ctx, fqgpu_timing *out) {
 }
 
 // ------------------------------------------------------------------ encode lanes
-EncLane *fq_next_lane(fqgpu_ctx *ctx) {
-  EncLane &l = ctx->lanes[ctx->next_lane % ctx->n_lanes];
+EncLane *fq_next_lane(fqgpu_ctx *ctx, size_t n_bases) {
+  EncLane &l = ctx->lanes[ctx->next_lane % fq_lanes_for(ctx, n_bases)];
   ctx->next_lane++;
   if (!l.st_seq) {
     // Both pipelines at the same priority: while the sequence chains were serial their stream
@@ -592,7 +592,7 @@ extern "C" int fqgpu_dblock_load_index(fqgpu_ctx *ctx, fqgpu_dblock *b, int stre
 }
 
 extern "C" int fqgpu_ctx_set_lanes(fqgpu_ctx *ctx, unsigned lanes) {
-  if (!ctx || lanes < 1 || lanes > FQ_MAX_LANES) return FQGPU_E_ARG;
+  if (!ctx || lanes > FQ_MAX_LANES) return FQGPU_E_ARG;  // (0: by block size)
   int rc = fqgpu_sync(ctx);
   if (rc) return rc;
   ctx->n_lanes = lanes;
@@ -966,7 +966,7 @@ extern "C" int fqgpu_ctx_reserve(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, 
       (rc = ctx->hp_parse.nl_pos.reserve((n_recs * 4 + 8) * 4)))
     return rc;
   const unsigned first = ctx->next_lane;
-  for (unsigned l = 0; l < ctx->n_lanes && !rc; l++) rc = fq_encode_launch(ctx, b, 0, nullptr, nullptr, true);
+  for (unsigned l = 0; l < fq_lanes_for(ctx, n_bases) && !rc; l++) rc = fq_encode_launch(ctx, b, 0, nullptr, nullptr, true);
   ctx->next_lane = first;
   return rc;
 }

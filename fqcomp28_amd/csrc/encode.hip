@@ -612,7 +612,7 @@ int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_re
 int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t wait, hipStream_t *done, bool reserve_only) {
   const unsigned R = (unsigned)b->n_recs;
   if (R == 0 || b->n_bases == 0) return FQGPU_E_ARG;
-  EncLane *lp = fq_next_lane(ctx);
+  EncLane *lp = fq_next_lane(ctx, b->n_bases);
   if (!lp) return FQGPU_E_NOMEM;
   EncLane &lane = *lp;
   hipStream_t st = lane.st_seq;

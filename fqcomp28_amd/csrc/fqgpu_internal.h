@@ -164,7 +164,7 @@ struct fqgpu_ctx {
   unsigned index_stride = 1u << 20;  // symbols between the snapshots of a decode index
   unsigned n_cus = 256;          // compute units of the device
   unsigned setfunc_wgs = 0;      // persistent workgroups of k_seq_setfunc (0 = default, see fqgpu_ctx_create)
-  unsigned n_lanes = 4, next_lane = 0;
+  unsigned n_lanes = 0, next_lane = 0;  // n_lanes 0 = by block size: fq_lanes_for()
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch
   DevBuf n_cnt32, n_off, scan_tmp;
@@ -182,7 +182,13 @@ struct fqgpu_ctx {
   hipStream_t hp_done = nullptr;      // the stream its last kernel runs on
 };
 
-EncLane *fq_next_lane(fqgpu_ctx *ctx);  // api.hip: round-robin, creates streams on first use
+EncLane *fq_next_lane(fqgpu_ctx *ctx, size_t n_bases);  // api.hip: round-robin, creates streams on first use
+// Blocks a handle keeps in flight when the caller has not said (fqgpu_ctx_set_lanes(ctx, 0), the default): four -- two
+// already fill the chip with 256 MiB blocks --, six for blocks of less than 48 M symbols (about 100 MiB), whose chains of
+// short kernels leave more gaps to fill: 16 x 64 MiB blocks 70.6 -> 75.6 GB/s (eight: 71.2).
+static inline unsigned fq_lanes_for(const fqgpu_ctx *ctx, size_t n_bases) {
+  return ctx->n_lanes ? ctx->n_lanes : (n_bases && n_bases < ((size_t)48 << 20) ? 6u : 4u);
+}
 
 struct fqgpu_dblock {
   int device = 0;

@@ -104,8 +104,9 @@ int fqgpu_ctx_set_seq_group(fqgpu_ctx *ctx, unsigned max_segments, unsigned min_
  * scratch of every encode lane): a worker calls it while it builds its workspace, so that its
  * first block does not pay for the allocations.  Optional; everything grows on demand. */
 int fqgpu_ctx_reserve(fqgpu_ctx *ctx, size_t raw_len, size_t n_recs, size_t n_bases);
-/* Number of blocks the handle keeps in flight (encode lanes, 1..8, default 4): each
- * fqgpu_dblock_encode goes to the next lane (own HIP streams and scratch). */
+/* Number of blocks the handle keeps in flight (encode lanes, 1..8; 0 = the default: four, six for
+ * blocks of less than 48 M symbols): each fqgpu_dblock_encode goes to the next lane (own HIP streams
+ * and scratch). */
 int fqgpu_ctx_set_lanes(fqgpu_ctx *ctx, unsigned lanes);
 /* Test hook: copies the device-built tables of one context out in zstd's memory
  * layout (FSE_CTable / FSE_DTable u32 words).  stream: 0 = sequence, 1 = quality. */

@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3, help="fresh processes per variant")
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions of `steps` steps inside a process")
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--lanes", type=int, default=4)
+    ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--spans", action="store_true")
     ap.add_argument("--child", default=None, help=argparse.SUPPRESS)
