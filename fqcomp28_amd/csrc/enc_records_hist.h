@@ -314,9 +314,9 @@ constexpr int K1Q_DEPTH = FQ_K1Q_DEPTH;  // quad chunks (256 symbols) whose wind
 __global__ void __launch_bounds__(256)
 k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
              const uint32_t *__restrict__ rec_start, unsigned R, unsigned n_sym, unsigned T,
-             uint16_t *__restrict__ tile_hist_seq, uint16_t *__restrict__ ckey_seq,
-             uint16_t *__restrict__ tile_hist_qual, uint16_t *__restrict__ ckey_qual, uint8_t *__restrict__ csym_qual,
-             uint32_t *__restrict__ n_cnt32, BlockResult *res) {
+             uint16_t *__restrict__ tile_hist_seq, uint8_t *__restrict__ ckey_seq,
+             uint16_t *__restrict__ tile_hist_qual, uint16_t *__restrict__ ckey_qual, uint8_t *__restrict__ first_seq,
+             uint8_t *__restrict__ first_qual, uint32_t *__restrict__ n_cnt32, BlockResult *res) {
   constexpr unsigned BS = SeqModel::B, BQ = QualModel::B;
   __shared__ uint32_t hist_s[BS];
   __shared__ uint32_t hist_q[BQ / 2];  // 16-bit counters, two per word (T <= 32768: they cannot wrap)
@@ -360,7 +360,7 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
 
       // ---- software pipeline over the chunks of 64 quads
       unsigned long long ws[K1Q_DEPTH], wq[K1Q_DEPTH];  // windows, already shifted: byte k = position p_hi - 7 + k
-      unsigned ef[K1Q_DEPTH], vm[K1Q_DEPTH], mm[K1Q_DEPTH], rr[K1Q_DEPTH];  // first encode index, valid mask (4 bits), missing bytes, record
+      unsigned ef[K1Q_DEPTH], vm[K1Q_DEPTH], mm[K1Q_DEPTH], rr[K1Q_DEPTH];  // first encode index, valid mask (4 bits; bit 4: the quad opens its record), missing bytes, record
       unsigned kc = 0;  // (uniform) cached record holding the first quad of the next chunk to be fetched
       auto fetch = [&](int slot, unsigned c) {
         const unsigned g0 = c << 6, g = g0 + lane;
@@ -389,10 +389,11 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
           const unsigned e = e_first + i;
           valid |= (on && i <= p_hi && e >= wb && e < we) ? 1u << i : 0u;
         }
+        valid |= (j4 == 0u && (valid & 1u)) ? 16u : 0u;  // the record's first symbol in encode order is this quad's first
         ws[slot] = a; wq[slot] = b; ef[slot] = e_first; vm[slot] = valid; mm[slot] = m; rr[slot] = r0 + k;
       };
       auto consume = [&](int slot) {
-        const unsigned valid = vm[slot], sh = 8u * mm[slot], e_first = ef[slot];
+        const unsigned opens = vm[slot] >> 4, valid = vm[slot] & 15u, sh = 8u * mm[slot], e_first = ef[slot];
         if (!valid) return;
         // -------- sequence
         const unsigned long long w = ws[slot] << sh;   // byte k = position p_hi - 7 + k (0 in front of the read)
@@ -432,13 +433,16 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
           cq[i] = ((((qb[i] > qc[i] ? qb[i] : qc[i]) << 6) + qa[i]) & 0xFFFu) | ((qb[i] == qc[i]) ? 0x1000u : 0u);
           bad_q |= ((valid >> i) & 1u) && qs_[i] >= (unsigned)QualModel::A;
         }
-        // -------- keys out, histograms
+        // -------- keys out, histograms.  The keys are the CONTEXTS alone (one byte / two bytes per symbol): the symbol at
+        // encode index e is part of the context at e - 1 -- the base in bits 7:6, the quality in bits 5:0 (the position in front
+        // of p + 1 is p) -- and K3 takes it from there; only a record's first symbol in encode order has no such neighbour
+        // and is left in first_seq / first_qual [record].  240 MB of symbols and key bytes less written here and read by K3.
+        if (opens) { first_seq[rr[slot]] = (uint8_t)(k16[0] >> 8); first_qual[rr[slot]] = (uint8_t)(qs_[0] & 63u); }
         if (valid == 0xFu) {
           struct __attribute__((packed)) P8 { uint32_t a, b; };
           struct __attribute__((packed)) P4 { uint32_t a; };
-          *reinterpret_cast<P8 *>(ckey_seq + e_first) = P8{k16[0] | (k16[1] << 16), k16[2] | (k16[3] << 16)};
+          *reinterpret_cast<P4 *>(ckey_seq + e_first) = P4{(k16[0] & 0xFFu) | ((k16[1] & 0xFFu) << 8) | ((k16[2] & 0xFFu) << 16) | (k16[3] << 24)};
           *reinterpret_cast<P8 *>(ckey_qual + e_first) = P8{cq[0] | (cq[1] << 16), cq[2] | (cq[3] << 16)};
-          *reinterpret_cast<P4 *>(csym_qual + e_first) = P4{(qs_[0] & 63u) | ((qs_[1] & 63u) << 8) | ((qs_[2] & 63u) << 16) | ((qs_[3] & 63u) << 24)};
 #pragma unroll
           for (unsigned i = 0; i < 4; i++) {
             atomicAdd(&hist_s[k16[i] & 0xFFu], 1u);
@@ -448,9 +452,8 @@ k_tile_hist2(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs
 #pragma unroll
           for (unsigned i = 0; i < 4; i++)
             if ((valid >> i) & 1u) {
-              ckey_seq[e_first + i] = (uint16_t)k16[i];
+              ckey_seq[e_first + i] = (uint8_t)k16[i];
               ckey_qual[e_first + i] = (uint16_t)cq[i];
-              csym_qual[e_first + i] = (uint8_t)(qs_[i] & 63u);
               atomicAdd(&hist_s[k16[i] & 0xFFu], 1u);
               atomicAdd(&hist_q[cq[i] >> 1], 1u << (16u * (cq[i] & 1u)));
             }

@@ -101,14 +101,24 @@ __device__ __forceinline__ void ts_clear_bitmap(TsRunMap &m) {
 // place in LDS, position stored to lpos16 -- stores only, nothing in the loop ever waits for global
 // memory); the other seven waves bring in the next batch of keys.  Then all waves write
 // the tile's runs: position-major, so that consecutive lanes store consecutive bytes.
-template <class M>
+// DERIVED: the keys are the contexts alone, as the fused K1 (k_tile_hist2) leaves them -- two bytes per quality symbol, ONE per
+// base --, and the symbol at encode index e is taken from the context at e - 1 (its low six bits / its top two: the position
+// in front of p + 1 is p); the first symbol of every record in encode order has no such neighbour and is patched in from
+// first_sym[record] once the tile is ranked.  Not DERIVED (keys of k_tile_hist<M>): u16 keys, sequence ctx | sym << 8,
+// quality symbols in csym.
+template <class M, bool DERIVED>
 __global__ void __launch_bounds__(TS_THREADS)
-k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ csym, unsigned n_sym,
+k_tile_partition(const void *__restrict__ ckey_v, const uint8_t *__restrict__ csym, unsigned n_sym,
                  const uint16_t *__restrict__ tile_hist, const uint32_t *__restrict__ tile_base,
                  uint8_t *__restrict__ sorted_sym, uint16_t *__restrict__ lpos16, uint2 *__restrict__ runs,
-                 uint32_t *__restrict__ run_count, unsigned long long *__restrict__ k6_status, unsigned *__restrict__ k6_counter) {
+                 uint32_t *__restrict__ run_count, unsigned long long *__restrict__ k6_status, unsigned *__restrict__ k6_counter,
+                 const uint32_t *__restrict__ rec_start, unsigned R, const uint8_t *__restrict__ first_sym) {
   constexpr unsigned B = M::B;
   constexpr bool QUAL = M::STREAM == 1;
+  constexpr bool K8 = DERIVED && !QUAL;  // one byte per key in memory
+  static_assert(DERIVED || QUAL || true, "");
+  const uint16_t *ckey = reinterpret_cast<const uint16_t *>(ckey_v);
+  const uint8_t *ckey8 = reinterpret_cast<const uint8_t *>(ckey_v);
   // K6's look-back starts from clean words: this kernel runs in front of it on the same stream and has a workgroup per tile
   // (a memset per stream and block less)
   if (k6_status != nullptr && threadIdx.x == 0) {
@@ -128,12 +138,7 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   // placed it and stored the position to global memory: half of this kernel's time was that one wave's loop.
   // The run map lives in the same bytes: it is built when the last batch has been ranked.
   constexpr unsigned NBUF = 2;
-#ifndef FQ_K3_SEQ_RANKER_PLACES
-#define FQ_K3_SEQ_RANKER_PLACES 0
-#endif
-  // sequence stream (FQ_K3_SEQ_RANKER_PLACES): the symbol is in the key, the ranking wave places it itself -- no symbol
-  // buffers, 50 KB of LDS, three workgroups per CU instead of two
-  constexpr bool PLACE = QUAL || !FQ_K3_SEQ_RANKER_PLACES;   // the loaders place the symbols
+  constexpr bool PLACE = true;   // the loaders place the symbols (a ranking wave that placed the sequence stream's itself -- no symbol buffers, three workgroups per CU -- measured the same)
   constexpr unsigned KB_BYTES = NBUF * (TS_BATCH / 8) * 16, SB_BYTES = PLACE ? NBUF * (TS_BATCH / 8) * 8 : 16;
   __shared__ __attribute__((aligned(16))) uint8_t stage_raw[(KB_BYTES + SB_BYTES) > sizeof(TsRunMap) ? (KB_BYTES + SB_BYTES) : sizeof(TsRunMap)];
   uint4 (*kb4)[TS_BATCH / 8] = reinterpret_cast<uint4 (*)[TS_BATCH / 8]>(stage_raw);
@@ -193,21 +198,47 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   const bool two = mt + NL < TS_BATCH / 8;
   uint4 rk0 = make_uint4(0, 0, 0, 0), rk1 = rk0;
   uint2 rs0 = make_uint2(0, 0), rs1 = rs0;
-  auto syms_of = [](const uint4 k) {  // sequence stream: the symbol is bits 9:8 of the key
+  unsigned rp0 = 0, rp1 = 0;  // DERIVED: the dword in front of the piece (its top key is the one at the piece's first index - 1)
+  auto syms_of = [](const uint4 k) {  // not DERIVED, sequence stream: the symbol is bits 9:8 of the key
     auto two_of = [](unsigned w) { return ((w >> 8) & 0xFFu) | ((w >> 24) << 8); };
     return make_uint2(two_of(k.x) | (two_of(k.y) << 16), two_of(k.z) | (two_of(k.w) << 16));
   };
-  auto request = [&](unsigned j) {  // batch j -> registers (loaders)
-    const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + e0 + j * TS_BATCH);  // 16-byte aligned; arrays are padded by a batch
-    const uint2 *gs = reinterpret_cast<const uint2 *>(csym + e0 + j * TS_BATCH);
-    rk0 = gk[mt];
-    if (two) rk1 = gk[mt + NL];
-    if (QUAL) { rs0 = gs[mt]; if (two) rs1 = gs[mt + NL]; }
+  // DERIVED: the eight symbols of a piece from the piece's keys and the key in front of it
+  auto derive = [](const uint4 k, unsigned prev) {
+    if (K8) {  // k.x, k.y: eight one-byte contexts; symbol = the context's bits 7:6
+      const unsigned t = (k.x >> 6) & 0x03030303u, u = (k.y >> 6) & 0x03030303u;
+      return make_uint2((prev >> 30) | (t << 8), (t >> 24) | (u << 8));
+    }
+    // eight 16-bit contexts; symbol = the context's bits 5:0
+    return make_uint2(((prev >> 16) & 63u) | ((k.x & 63u) << 8) | (((k.x >> 16) & 63u) << 16) | ((k.y & 63u) << 24),
+                      ((k.y >> 16) & 63u) | ((k.z & 63u) << 8) | (((k.z >> 16) & 63u) << 16) | ((k.w & 63u) << 24));
   };
+  auto keys16_of = [](const uint4 k) {  // the piece as eight 16-bit keys for the batch buffer
+    if (K8) return make_uint4(__builtin_amdgcn_perm(0u, k.x, 0x0C010C00u), __builtin_amdgcn_perm(0u, k.x, 0x0C030C02u),
+                              __builtin_amdgcn_perm(0u, k.y, 0x0C010C00u), __builtin_amdgcn_perm(0u, k.y, 0x0C030C02u));
+    return k;
+  };
+  // piece `piece` of the batch that starts at encode index eb: its keys (K8: in .x, .y) and the dword in front of them
+  auto load_piece = [&](unsigned eb, unsigned piece, uint4 &k, unsigned &prev, uint2 &sy) {
+    if (K8) {
+      const uint2 v = reinterpret_cast<const uint2 *>(ckey8 + eb)[piece];
+      k = make_uint4(v.x, v.y, 0u, 0u);
+      prev = eb + 8u * piece ? reinterpret_cast<const uint32_t *>(ckey8 + eb)[2 * (int)piece - 1] : 0u;
+    } else {
+      k = reinterpret_cast<const uint4 *>(ckey + eb)[piece];  // 16-byte aligned; arrays are padded by a batch
+      if (DERIVED) prev = eb + 8u * piece ? reinterpret_cast<const uint32_t *>(ckey + eb)[4 * (int)piece - 1] : 0u;
+      else if (QUAL) sy = reinterpret_cast<const uint2 *>(csym + eb)[piece];
+    }
+  };
+  auto request = [&](unsigned j) {  // batch j -> registers (loaders)
+    load_piece(e0 + j * TS_BATCH, mt, rk0, rp0, rs0);
+    if (two) load_piece(e0 + j * TS_BATCH, mt + NL, rk1, rp1, rs1);
+  };
+  auto syms_for = [&](const uint4 k, unsigned prev, const uint2 sy) { return DERIVED ? derive(k, prev) : QUAL ? sy : syms_of(k); };
   auto deposit = [&](unsigned j) {  // registers -> LDS buffer of batch j (loaders)
-    kb4[j % NBUF][mt] = rk0;
-    if (PLACE) sb8[j % NBUF][mt] = QUAL ? rs0 : syms_of(rk0);
-    if (two) { kb4[j % NBUF][mt + NL] = rk1; if (PLACE) sb8[j % NBUF][mt + NL] = QUAL ? rs1 : syms_of(rk1); }
+    kb4[j % NBUF][mt] = keys16_of(rk0);
+    sb8[j % NBUF][mt] = syms_for(rk0, rp0, rs0);
+    if (two) { kb4[j % NBUF][mt + NL] = keys16_of(rk1); sb8[j % NBUF][mt + NL] = syms_for(rk1, rp1, rs1); }
   };
   // batch j has been ranked: its buffer holds positions where the keys were.  Symbols to their places, positions out.
   auto finish_piece = [&](unsigned j, unsigned piece) {
@@ -241,12 +272,13 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   // every barrier for the batch they have just requested and for their position stores (fire and forget).
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   {  // batch 0 by everybody, straight to LDS
-    const uint4 *gk = reinterpret_cast<const uint4 *>(ckey + e0);
-    const uint2 *gs = reinterpret_cast<const uint2 *>(csym + e0);
     for (unsigned i = tid; i < TS_BATCH / 8; i += TS_THREADS) {
-      const uint4 k = gk[i];
-      kb4[0][i] = k;
-      if (PLACE) sb8[0][i] = QUAL ? gs[i] : syms_of(k);
+      uint4 k;
+      unsigned prev = 0;
+      uint2 sy = make_uint2(0, 0);
+      load_piece(e0, i, k, prev, sy);
+      kb4[0][i] = keys16_of(k);
+      sb8[0][i] = syms_for(k, prev, sy);
     }
   }
   if (wave != 0 && nbatch > 1) request(1);
@@ -272,7 +304,7 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
         for (unsigned g = 0; g < G; g++) {
           const unsigned i = cb + 64 * g + lane;
           key[g] = kb[i];
-          sy[g] = PLACE ? (unsigned)sbb[i] : key[g] >> 8;
+          sy[g] = (unsigned)sbb[i];
         }
 #pragma unroll
         for (unsigned g = 0; g < G; g++) {
@@ -329,7 +361,6 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
         for (unsigned g = 0; g < G; g++) {
           const unsigned i = cb + 64 * g + lane;
           kb[i] = (uint16_t)pos[g];
-          if (!PLACE) lsym[i < nb ? pos[g] : TS_TILE + lane] = (uint8_t)(key[g] >> 8);
         }
       }
 #ifdef FQGPU_EXPERIMENTS
@@ -346,7 +377,23 @@ k_tile_partition(const uint16_t *__restrict__ ckey, const uint8_t *__restrict__ 
   TS_PROF(PS + 1);
 
   // ---- the tile's runs, in context order: cur16[c] is now the END of context c's run
-  __syncthreads();  // (also drains the ranking wave's position stores) the batch buffers are dead: the run map takes their place
+  __syncthreads();  // (also drains the position stores) the batch buffers are dead: the run map takes their place
+  if (DERIVED) {
+    // the first symbol of every record that starts in this tile: its position comes back from lpos16 (this workgroup's own
+    // stores, complete behind the barrier above; read past the L1), its symbol from K1's side table
+    unsigned lo = 0, hi = R;  // first record with rec_start >= e0
+    while (lo < hi) {
+      const unsigned mid = (lo + hi) >> 1;
+      if (rec_start[mid] < e0) lo = mid + 1; else hi = mid;
+    }
+    for (unsigned r = lo + tid; r < R; r += TS_THREADS) {
+      const unsigned e = rec_start[r];
+      if (e >= e0 + nt) break;
+      const unsigned w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(lpos16) + (e >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lsym[(w >> (16u * (e & 1u))) & 0xFFFFu] = first_sym[r];
+    }
+    __syncthreads();
+  }
   ts_clear_bitmap<TS_THREADS>(rm);
   unsigned long long my_mask[(NCHUNK + TS_WAVES - 1) / TS_WAVES];
   unsigned my_beg[(NCHUNK + TS_WAVES - 1) / TS_WAVES], my_len[(NCHUNK + TS_WAVES - 1) / TS_WAVES];

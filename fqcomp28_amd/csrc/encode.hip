@@ -259,8 +259,18 @@ int encode_stream(fqgpu_ctx *ctx, EncLane &lane, hipStream_t st, fqgpu_dblock *b
   uint4 *ts_edges = reinterpret_cast<uint4 *>(sync_base + sync_edges_off);
   if (tile_path) {
     if (!dbg_off)
-      hipLaunchKernelGGL(k_tile_partition<M>, dim3(n_tiles), dim3(TS_THREADS), 0, st, ckey, csym, n_sym, sc.tile_hist.as<uint16_t>(),
-                         sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), lpos16, sc.tile_runs.as<uint2>(), ts_run_count, ts_status, ts_counter);
+    {
+      // keys of the fused K1: contexts alone, the symbols derived from them (first symbols of the records from lane.first_sym)
+      const uint8_t *first_sym = lane.first_sym.as<uint8_t>() + (M::STREAM ? R : 0u);
+      if (fused_k1(ctx))
+        hipLaunchKernelGGL((k_tile_partition<M, true>), dim3(n_tiles), dim3(TS_THREADS), 0, st, ckey, csym, n_sym, sc.tile_hist.as<uint16_t>(),
+                           sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), lpos16, sc.tile_runs.as<uint2>(), ts_run_count, ts_status, ts_counter,
+                           rec_start, R, first_sym);
+      else
+        hipLaunchKernelGGL((k_tile_partition<M, false>), dim3(n_tiles), dim3(TS_THREADS), 0, st, ckey, csym, n_sym, sc.tile_hist.as<uint16_t>(),
+                           sc.tile_base.as<uint32_t>(), sc.sorted_sym.as<uint8_t>(), lpos16, sc.tile_runs.as<uint2>(), ts_run_count, ts_status, ts_counter,
+                           rec_start, R, (const uint8_t *)nullptr);
+    }
   } else if (!dbg_off && serial_seq) {
     if (ctx->lds_atomics_ordered)
       hipLaunchKernelGGL(k_scatter_seq<true>, dim3(n_tiles), dim3(64), 0, st, ckey, n_sym, T, sc.tile_base.as<uint32_t>(),
@@ -558,7 +568,7 @@ int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_re
   int rc = FQGPU_OK;
   do {
     if ((rc = lane.rec_start.reserve((size_t)(R + 1) * 4)) || (rc = lane.n_cnt32.reserve((size_t)R * 8)) ||
-        (rc = readlens.reserve((size_t)R * 2)) || (rc = result.reserve(sizeof(BlockResult))) ||
+        (rc = readlens.reserve((size_t)R * 2)) || (rc = result.reserve(sizeof(BlockResult))) || (rc = lane.first_sym.reserve((size_t)R * 2 + 16)) ||
         (rc = reserve_k1<SeqModel>(ss, n_sym)) || (rc = reserve_k1<QualModel>(sq, n_sym)) ||
         (rc = sq.slot_of.reserve(n_pad * 2)) || (rc = sq.sorted_sym.reserve(padded)) || (rc = sq.tile_base.reserve((size_t)n_tiles * B * 4)) ||
         (rc = sq.group_sum.reserve((size_t)n_groups * B * 4)) || (rc = sq.ctx_arrays.reserve((size_t)(4 * B + 3) * 4)) ||
@@ -573,18 +583,18 @@ int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_re
                        readlens.as<uint16_t>(), n_cnt32, lens32, (BlockResult *)nullptr);
     if ((rc = fq_scan_u32_to_u32(st, lens32, R, rec_start, lane.scan_tmp))) break;
     hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, raw_dev, recs_dev, rec_start, R, n_sym, TS_TILE,
-                       ss.tile_hist.as<uint16_t>(), ss.keys.as<uint16_t>(), sq.tile_hist.as<uint16_t>(), kq,
-                       reinterpret_cast<uint8_t *>(kq + n_pad), n_cnt32, res);
+                       ss.tile_hist.as<uint16_t>(), ss.keys.as<uint8_t>(), sq.tile_hist.as<uint16_t>(), kq,
+                       lane.first_sym.as<uint8_t>(), lane.first_sym.as<uint8_t>() + R, n_cnt32, res);
     hipLaunchKernelGGL(k_group_sum<uint16_t>, dim3((B + 255) / 256, n_groups), dim3(256), 0, st, sq.tile_hist.as<uint16_t>(), n_tiles, B, sq.group_sum.as<uint32_t>());
     hipLaunchKernelGGL(k_group_prefix, dim3((B + 255) / 256), dim3(256), 0, st, sq.group_sum.as<uint32_t>(), n_groups, B, arrays);
     hipLaunchKernelGGL(k_ctx_layout, dim3(1), dim3(1024), 0, st, B, S, arrays, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_tile_base<uint16_t>, dim3((B + 255) / 256, n_groups), dim3(256), 0, st, sq.tile_hist.as<uint16_t>(), sq.group_sum.as<uint32_t>(),
                        arrays + B, n_tiles, B, sq.tile_base.as<uint32_t>());
     // (the rank only has to be a permutation here, not a stable one: no lane-ordered atomics are relied on)
-    hipLaunchKernelGGL(k_tile_partition<QualModel>, dim3(n_tiles), dim3(TS_THREADS), 0, st, kq, reinterpret_cast<uint8_t *>(kq + n_pad), n_sym,
+    hipLaunchKernelGGL((k_tile_partition<QualModel, true>), dim3(n_tiles), dim3(TS_THREADS), 0, st, kq, (const uint8_t *)nullptr, n_sym,
                        sq.tile_hist.as<uint16_t>(), sq.tile_base.as<uint32_t>(), sq.sorted_sym.as<uint8_t>(),
                        reinterpret_cast<uint16_t *>(sq.slot_of.as<uint32_t>()), sq.tile_runs.as<uint2>(), sq.tile_sync.as<uint32_t>(),
-                       (unsigned long long *)nullptr, (unsigned *)nullptr);
+                       (unsigned long long *)nullptr, (unsigned *)nullptr, rec_start, R, lane.first_sym.as<uint8_t>() + R);
     hipLaunchKernelGGL(k_hist_sorted_qual, dim3((max_segs + 3) / 4), dim3(256), 0, st, sq.sorted_sym.as<uint8_t>(), arrays, S, counts_dev);
     BlockResult h;
     if (hipMemcpyAsync(&h, res, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
@@ -595,7 +605,7 @@ int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_re
     }
   } while (0);
   (void)hipStreamSynchronize(st);
-  DevBuf *own[] = {&readlens, &result, &lane.rec_start, &lane.n_cnt32, &lane.n_off, &lane.scan_tmp};
+  DevBuf *own[] = {&readlens, &result, &lane.rec_start, &lane.n_cnt32, &lane.n_off, &lane.scan_tmp, &lane.first_sym};
   for (DevBuf *b : own) b->release();
   for (EncScratch *e : {&ss, &sq}) {
     DevBuf *eb[] = {&e->slot_of, &e->keys, &e->sorted_sym, &e->out16, &e->tile_hist, &e->tile_base, &e->group_sum, &e->ctx_arrays,
@@ -622,6 +632,7 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
   if ((rc = lane.rec_start.reserve((size_t)(R + 1) * 4))) return rc;
   if ((rc = lane.n_cnt32.reserve((size_t)R * 4 * 2))) return rc;  // n_cnt32 | lens32
   if ((rc = lane.n_off.reserve((size_t)(R + 1) * 4))) return rc;
+  if ((rc = lane.first_sym.reserve((size_t)R * 2 + 16))) return rc;
   uint32_t *n_cnt32 = lane.n_cnt32.as<uint32_t>();
   uint32_t *lens32 = n_cnt32 + R;
   uint32_t *rec_start = lane.rec_start.as<uint32_t>();
@@ -652,12 +663,11 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
   if (fused) {  // K1 of both streams in one pass, in front of the fork
     const unsigned n_sym = (unsigned)b->n_bases, n_tiles = (n_sym + TS_TILE - 1) / TS_TILE;
     if ((rc = reserve_k1<SeqModel>(lane.enc[0], n_sym)) || (rc = reserve_k1<QualModel>(lane.enc[1], n_sym))) return rc;
-    const size_t n_pad = ((size_t)n_sym + SC_BATCH_SEQ + 15) & ~(size_t)15;
     uint16_t *kq = lane.enc[1].keys.as<uint16_t>();
     FQ_SPAN_BEGIN("tile_hist2");
     if (!fq_debug_skipk("k1")) hipLaunchKernelGGL(k_tile_hist2, dim3(n_tiles), dim3(256), 0, st, b->raw, b->recs, rec_start, R, n_sym, TS_TILE,
-                       lane.enc[0].tile_hist.as<uint16_t>(), lane.enc[0].keys.as<uint16_t>(), lane.enc[1].tile_hist.as<uint16_t>(), kq,
-                       reinterpret_cast<uint8_t *>(kq + n_pad), n_cnt32, b->result);
+                       lane.enc[0].tile_hist.as<uint16_t>(), lane.enc[0].keys.as<uint8_t>(), lane.enc[1].tile_hist.as<uint16_t>(), kq,
+                       lane.first_sym.as<uint8_t>(), lane.first_sym.as<uint8_t>() + R, n_cnt32, b->result);
     FQ_SPAN_END();
   }
   FQ_HIP(hipEventRecord(lane.ev_fork, lane.st_seq));

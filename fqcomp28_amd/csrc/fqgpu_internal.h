@@ -142,6 +142,7 @@ struct EncLane {
   DevBuf rec_start;   // u32 [R+1] first encode index of each record
   DevBuf n_cnt32;     // u32 [R] N count | u32 [R] length
   DevBuf n_off;       // u32 [R+1]
+  DevBuf first_sym;   // u8 [R] sequence | u8 [R] quality: every record's first symbol in encode order (fused K1 -> K3)
   DevBuf scan_tmp;
   EncScratch enc[2];
 };
