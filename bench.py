@@ -734,12 +734,15 @@ def main():
         od = [other_data(F, Oc, device, lanes, 5, "binned qualities: four levels at 5/10/15/70 %, kept w.p. 0.85 (synth mode 3)", 3, 1024, 256, 128, 16),
               other_data(F, Oc, device, lanes, 5, "constant: every base A, every quality F (synth mode 5)", 5, 1024, 256, 128, 16),
               other_data(F, Oc, device, lanes, 5, "BASELINE configs[3]: 256 MiB, length U[50,300], 1 % N (synth mode 4), in -R 64 blocks", 4, 256, 64, 128, 0)]
+        od.append(other_data(F, Oc, device, lanes, 5, "two quality levels '-' / 'F' i.i.d. at 30/70 % (synth mode 6): every quality segment needs its full "
+                             "entry-state -> exit-state function (the last opaque class)", 6, 1024, 256, 128, 0, classes=True))
+        extra["encode_two_levels_MBps"] = od[3]["MBps"]
         real_blocks = make_real_workload(F, 1024 << 20, 256 << 20)
         od.append(other_data(F, Oc, device, lanes, 5, "REAL reads: the reference's 2 851 test reads of SRR065390 (100 bp, N runs, '#' tails) tiled to 4 x 256 MiB "
                              "with fresh read ids, tables from the first 128 MiB", None, 1024, 256, 128, 16, blocks=real_blocks, classes=True))
         del real_blocks
-        extra["encode_real_MBps"] = od[3]["MBps"]
-        extra["decode_real_ns_per_symbol"] = od[3].get("decode_ns_per_symbol_per_lane")
+        extra["encode_real_MBps"] = od[4]["MBps"]
+        extra["decode_real_ns_per_symbol"] = od[4].get("decode_ns_per_symbol_per_lane")
         extra["encode_binned_MBps"], extra["encode_constant_MBps"], extra["encode_config4_MBps"] = (o["MBps"] for o in od[:3])
         extra["decode_binned_ns_per_symbol"] = od[0].get("decode_ns_per_symbol_per_lane")
         extra["decode_constant_ns_per_symbol"] = od[1].get("decode_ns_per_symbol_per_lane")

@@ -110,6 +110,13 @@ extern "C" size_t fqgpu_synth_fastq(uint8_t *dst, size_t cap, int mode, uint64_t
     } else if (mode == 5) {  // constant: one base, one quality (one context per stream from the fourth symbol on)
       memset(s, 'A', L);
       memset(q, 'F', L);
+    } else if (mode == 6) {  // two quality levels, i.i.d. at 30/70 %, nothing else: no reset symbol, no narrow symbol, no uniform segment
+      uint64_t r = 0;
+      for (unsigned i = 0; i < L; i++) {
+        if ((i & 3u) == 0) r = g.next();
+        q[i] = (uint8_t)(((r & 0xFFFFu) < 19661u) ? '-' : 'F');  // 0.3 * 65536
+        r >>= 16;
+      }
     } else {
       for (unsigned i = 0; i < L; i++) q[i] = (uint8_t)(33 + phred_normal(g));
       if (mode == 4)

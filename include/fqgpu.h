@@ -261,7 +261,9 @@ long fqgpu_parse_fastq(const uint8_t *raw, size_t len, fqgpu_rec *recs, size_t c
  * the data (bench.py: encode_binned_MBps, encode_constant_MBps): mode 3: mode 2's bases with binned
  * qualities -- '#', '-', '8', 'F' at 5/10/15/70 %, the previous position's level kept w.p. 0.85 (no
  * symbol with a single table cell, long runs of one context); mode 5: every base 'A', every quality
- * 'F' (one context per stream).  Writes whole records only; returns bytes written. */
+ * 'F' (one context per stream); mode 6: mode 2's bases, two quality levels '-' / 'F' i.i.d. at 30/70 %
+ * (every quality segment needs its full entry-state -> exit-state function).  Writes whole records
+ * only; returns bytes written. */
 size_t fqgpu_synth_fastq(uint8_t *dst, size_t cap, int mode, uint64_t seed, uint64_t first_read_id,
                          uint64_t *n_reads_out);
 

@@ -534,6 +534,31 @@ def test_constant_phred0_qualities_fill_whole_tiles_with_one_context(F):
 
 
 @pytest.mark.parametrize("segment", [1024, 4096])
+@pytest.mark.parametrize("size_mib", [3, 24])
+def test_two_quality_levels_every_segment_needs_its_full_function(F, segment, size_mib):
+    """Synth mode 6: two quality levels at 30/70 %, nothing else -- no reset symbol, no narrow (anchor) symbol, no uniform
+    segment: every quality segment is opaque and gets its entry state from full segment functions composed along chains of
+    hundreds to thousands of segments (eight contexts hold the whole stream: three-level resolves, combining ranker in K3).
+    Bit for bit, both directions.  (bench.py: encode_two_levels_MBps.)"""
+    raw, recs = _synth(F, 6, size_mib << 20)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    ctx.set_chain_params(segment)
+    b = ctx.dblock(raw, recs)
+    b.encode()
+    g = b.fetch()
+    assert_same_encoding(dict(g, rc=b.status()[0]), e)
+    cls = b.qual_segment_classes()
+    assert cls["opaque"] > 0.9 * sum(cls.values()) and cls["transparent"] == 0, cls
+    b.wipe()
+    ctx.decode_dblocks([b])
+    assert b.status()[0] == 0 and np.array_equal(b.fetch_raw(), raw)
+    b.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("segment", [1024, 4096])
 @pytest.mark.parametrize("quals", ["binned", "two_levels_rare_third"])
 def test_quality_tables_without_reset_symbols(F, quals, segment):
     """Binned qualities: no symbol has a normalised count of 1, so (almost) every quality segment is

@@ -64,7 +64,7 @@ def child(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("libs", nargs="*", help="name=path")
-    ap.add_argument("--data", default="synth", choices=["synth", "real", "binned", "constant", "config3", "config4"])
+    ap.add_argument("--data", default="synth", choices=["synth", "real", "binned", "constant", "two_levels", "config3", "config4"])
     ap.add_argument("--rounds", type=int, default=3, help="fresh processes per variant")
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions of `steps` steps inside a process")
     ap.add_argument("--steps", type=int, default=5)
@@ -85,7 +85,7 @@ def main():
     elif args.data == "config4":
         blocks = bench.make_workload(F0, 256 << 20, 64 << 20, seed=28, mode=4)
     else:
-        blocks = bench.make_workload(F0, 1 << 30, 256 << 20, seed=28, mode={"synth": 2, "binned": 3, "constant": 5}[args.data])
+        blocks = bench.make_workload(F0, 1 << 30, 256 << 20, seed=28, mode={"synth": 2, "binned": 3, "constant": 5, "two_levels": 6}[args.data])
     sft, qft = bench.sample_tables(F0, blocks, 128 << 20, 0)
     raw_bytes = sum(r.size for r, _ in blocks)
     path = "/dev/shm/ab_bench_%d.npz" % os.getpid()

@@ -20,7 +20,7 @@ elif kind == "config3":
 elif kind == "config4":
     blocks = bench.make_workload(F, 256 << 20, 64 << 20, seed=28, mode=4)
 else:
-    blocks = bench.make_workload(F, 1 << 30, 256 << 20, seed=28, mode={"synth": 2, "binned": 3, "constant": 5}[kind])
+    blocks = bench.make_workload(F, 1 << 30, 256 << 20, seed=28, mode={"synth": 2, "binned": 3, "constant": 5, "two_levels": 6}[kind])
 sft, qft = bench.sample_tables(F, blocks, 128 << 20, 0)
 ctx = F.Context(sft, qft)
 ctx.set_lanes(lanes)
