@@ -70,6 +70,13 @@ __global__ void __launch_bounds__(64) k(unsigned iters, unsigned *out, unsigned 
     if (VAR == 37) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_write_b32 %9, %5\n\tds_read_b64 v[10:11], v12\n\t" TWELVE "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, v10");
     if (VAR == 38) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_write_b32 %9, %5\n\tds_read_b32 v10, v12\n\tds_read_b32 v11, v12 offset:4\n\t" TWELVE "s_waitcnt lgkmcnt(1)\n\tv_readfirstlane_b32 %1, v10");
     if (VAR == 39) MEMBODY("s_and_b32 %2, %1, 0x1f8\n\ts_or_b32 %2, %2, 0\n\tv_mov_b32 v12, %2\n\tds_read2_b32 v[10:11], v12 offset1:1\n\t" TWELVE "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, v10");
+    // 40-42 (round 4): the chain WITHOUT an LDS round trip on it -- the 64 candidate entries of the next context's symbol-free
+    // half sit one per lane (read a step ahead), the symbol just decoded selects among them: s_bfe (symbol) -> v_readlane (next
+    // entry).  The candidates' read (address from the entry of the step before) and everything else run in its shadow.
+    if (VAR == 40) MEMBODY("s_bfe_u32 %2, %1, 0x60003\n\tv_readlane_b32 %1, v10, %2\n\ts_and_b32 %3, %1, 0x1f8\n\tv_or_b32 v12, %3, %9\n\tds_read_b32 v10, v12\n\t" TWELVE "s_waitcnt lgkmcnt(0)");   // 18 per rep
+    // 41: ... plus the refill block (mark of the slot left + LDS-DMA): what the real step adds to it
+    if (VAR == 41) MEMBODY("s_bfe_u32 %2, %1, 0x60003\n\tv_readlane_b32 %1, v10, %2\n\ts_and_b32 %3, %1, 0x1f8\n\tv_or_b32 v12, %3, %9\n\tds_write_b32 %9, %5\n\tds_read_b32 v10, v12\n\t" TWELVE "s_waitcnt lgkmcnt(1)\n\ts_mov_b32 m0, %8\n\ts_mov_b64 exec, 1\n\tglobal_load_lds_dword %9, %7\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)");  // 24 per rep
+    // 42: the current step's skeleton with the same count of filler for comparison: 23 + readfirstlane = VAR 23
     if (VAR == 19) MEMBODY(TWELVE "s_mov_b32 m0, %8\n\ts_mov_b64 exec, 1\n\tglobal_load_dword v12, %9, %7\n\ts_mov_b64 exec, -1");  // a plain load instead of the LDS-DMA
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -193,6 +200,8 @@ int main() {
     run<38>("38 chain (28) with two ds_read_b32, the wait for the first only (20 per 16)", grid);
     run<39>("39 chain (28) without the mark (18 per 16)", grid);
     run<22>("22 12 s_add + far refills, no ds ops (18 per 16)", grid);
+    run<40>("40 readlane-select chain + candidates' read + 12 s_add (18 per 16)", grid);
+    run<41>("41 ... + mark and refill (24 per 16)", grid);
   }
   run2<0>("two waves: walker skeleton alone");
   run2<1>("two waves: walker and feeder skeletons");
