@@ -38,7 +38,7 @@ def last_json(path):
 # bench.py's span labels -> the kernel(s) launched inside them
 SPAN_KERNELS = {
     "tile_hist2": ["k_tile_hist2"],
-    "seq.scatter": ["k_tile_partition<SeqModel>"], "qual.scatter": ["k_tile_partition<QualModel>"],
+    "seq.scatter": ["k_tile_partition<SeqModel, true>"], "qual.scatter": ["k_tile_partition<QualModel, true>"],
     "seq.setfunc": ["k_seq_setfunc<32u, true>"], "seq.chains": ["k_seq_emit"], "seq.resolve": ["k_seq_resolve<32u>"],
     "qual.stage1": ["k_seg_stage1<QualModel, 32u>"], "qual.heads": ["k_seg_heads<QualModel>"], "qual.walk2": ["k_seg_walk<QualModel, 2>"],
     "qual.scan": ["k_seg_scan<QualModel>"],
@@ -86,7 +86,7 @@ with open(R + "gpurun_out/%s_pmc_hbm_traffic_per_launch.csv" % TAG, "w") as f:
     for o in out:
         f.write("\"%s\",%d,%.1f,%.1f,%.1f\n" % o)
 # the PMC passes run 1 warm-up + 1 table + 1 timed step of 4 blocks = 12 block encodes (memsets are not kernels of ours)
-n_block_encodes = max(o[1] for o in out if o[0].startswith("k_tile_partition<QualModel>"))
+n_block_encodes = max(o[1] for o in out if o[0].startswith("k_tile_partition<QualModel"))
 block_mb = sum(o[4] * o[1] for o in out if not o[0].startswith(skip)) / n_block_encodes
 print("HBM MB per 256 MiB block (all encode kernels, FETCH doubled):", round(block_mb, 1), "over", n_block_encodes, "block encodes")
 for o in out[:14]:

@@ -37,7 +37,7 @@ def last_json(path):
 # bench.py's span labels -> the kernel(s) launched inside them
 SPAN_KERNELS = {
     "tile_hist2": ["k_tile_hist2"],
-    "seq.scatter": ["k_tile_partition<SeqModel>"], "qual.scatter": ["k_tile_partition<QualModel>"],
+    "seq.scatter": ["k_tile_partition<SeqModel, true>"], "qual.scatter": ["k_tile_partition<QualModel, true>"],
     "seq.setfunc": ["k_seq_setfunc<32u, true>"], "seq.chains": ["k_seq_emit"], "seq.resolve": ["k_seq_resolve<32u>"],
     "qual.stage1": ["k_seg_stage1<QualModel, 32u>"], "qual.heads": ["k_seg_heads<QualModel>"], "qual.walk2": ["k_seg_walk<QualModel, 2>"],
     "qual.scan": ["k_seg_scan<QualModel>"],
