@@ -291,7 +291,7 @@ EncLane *fq_next_lane(fqgpu_ctx *ctx, size_t n_bases) {
 }
 
 static void free_lane(EncLane &l) {
-  DevBuf *bufs[] = {&l.rec_start, &l.n_cnt32, &l.n_off, &l.scan_tmp, &l.first_sym};
+  DevBuf *bufs[] = {&l.rec_start, &l.n_cnt32, &l.n_off, &l.scan_tmp, &l.first_sym, &l.rscan};
   for (DevBuf *b : bufs) b->release();
   for (int s = 0; s < 2; s++) {
     EncScratch &e = l.enc[s];

@@ -51,9 +51,112 @@ k_readlens(const fqgpu_rec *__restrict__ recs, unsigned R, uint16_t *__restrict_
     n_cnt32[r] = 0;
   }
 }
-__global__ void __launch_bounds__(256)
-k_ncount16(const uint32_t *__restrict__ n_cnt32, unsigned R, uint16_t *__restrict__ n_count) {
-  for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) n_count[r] = (uint16_t)n_cnt32[r];
+// ------------------------------------------------------------------ record-level scans in ONE launch each
+// Round 3: k_readlens + three scan kernels in front of K1 and k_ncount16 + three scan kernels + k_store_npos_len in front
+// of k_npos -- nine launches of a few microseconds of work each on every block's critical path.  Here one kernel per
+// scan: a workgroup takes 2048 records (by ticket, so that it only ever waits for workgroups that already run), scans
+// them, publishes its total in status[chunk] and finds its base by a decoupled look-back, as K6 does for the tiles' bit
+// counts: value, flag and EPOCH travel in one 8-byte word (relaxed agent-scope atomics, no fence).  The epoch -- a launch
+// counter the host keeps per lane -- makes words of earlier launches read as "not there yet", so nothing is zeroed in
+// between; tickets are counted on from launch to launch (the host passes the count before this launch).
+//   MODE 0  lengths from the record table: readlens (u16), rec_start (u32 [R + 1], exclusive), n_cnt32 zeroed for K1,
+//           the block's result zeroed (first kernel of an encode)
+//   MODE 1  N counts left by K1: n_count (u16), n_off (u32 [R + 1]), result->n_pos_len
+constexpr unsigned RSCAN_THREADS = 256, RSCAN_PER = 8, RSCAN_CHUNK = RSCAN_THREADS * RSCAN_PER;
+// exclusive scan of one value per thread over a workgroup of RSCAN_THREADS; *total = sum (all threads call)
+__device__ __forceinline__ unsigned ts_block_scan_r(unsigned v, unsigned *wsum, unsigned *total) {
+  unsigned inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(inc, d);
+    if (fq_lane() >= (unsigned)d) inc += o;
+  }
+  const unsigned w = threadIdx.x >> 6;
+  if (fq_lane() == 63) wsum[w] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (unsigned i = 0; i < 4; i++) {
+    const unsigned s = wsum[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+
+constexpr unsigned long long RSCAN_FLAG_AGG = 1ull << 38, RSCAN_FLAG_INCL = 2ull << 38, RSCAN_VAL_MASK = (1ull << 38) - 1ull;
+
+template <int MODE>
+__global__ void __launch_bounds__(RSCAN_THREADS)
+k_record_scan(const fqgpu_rec *__restrict__ recs, uint32_t *__restrict__ n_cnt32, unsigned R, uint16_t *__restrict__ out16,
+              uint32_t *__restrict__ out_prefix, unsigned long long *__restrict__ status, unsigned *__restrict__ ticket,
+              unsigned ticket_base, unsigned epoch, BlockResult *res) {
+  __shared__ unsigned wsum[RSCAN_THREADS / 64], s_chunk;
+  __shared__ unsigned long long s_base;
+  const unsigned tid = threadIdx.x, lane = fq_lane(), wave = tid >> 6;
+  if (tid == 0) s_chunk = atomicAdd(ticket, 1u) - ticket_base;
+  __syncthreads();
+  const unsigned chunk = s_chunk, n_chunks = gridDim.x;
+  if (MODE == 0 && chunk == 0 && tid < sizeof(BlockResult) / 4) reinterpret_cast<uint32_t *>(res)[tid] = 0u;  // the block's result starts clean
+  const unsigned r0 = chunk * RSCAN_CHUNK + tid * RSCAN_PER;
+  unsigned v[RSCAN_PER], sum = 0;
+#pragma unroll
+  for (unsigned i = 0; i < RSCAN_PER; i++) {
+    const unsigned r = r0 + i;
+    v[i] = r < R ? (MODE == 0 ? recs[r].len : n_cnt32[r]) : 0u;
+    sum += v[i];
+  }
+  unsigned tot;
+  unsigned off = ts_block_scan_r(sum, wsum, &tot);
+  if (wave == 0) {
+    const unsigned long long ep = (unsigned long long)epoch << 40;
+    if (lane == 0)
+      __hip_atomic_store(&status[chunk], ep | (chunk == 0 ? RSCAN_FLAG_INCL : RSCAN_FLAG_AGG) | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long excl = 0;
+    if (chunk > 0) {
+      int first = (int)chunk - 1;  // lane l looks at chunk first - l
+      for (;;) {
+        const int idx = first - (int)lane;
+        unsigned long long st = ep | RSCAN_FLAG_AGG;  // (in front of chunk 0: empty aggregates)
+        if (idx >= 0) {
+          for (;;) {
+            st = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((st >> 40) == (unsigned long long)epoch && ((st >> 38) & 3ull) != 0ull) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        const unsigned long long incl_mask = __ballot(((st >> 38) & 3ull) == 2ull);
+        const unsigned stop = incl_mask ? (unsigned)__ffsll((long long)incl_mask) - 1u : 64u;  // nearest inclusive total
+        unsigned long long x = lane <= stop ? (st & RSCAN_VAL_MASK) : 0ull;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+        excl += x;
+        if (incl_mask || first < 64) break;
+        first -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&status[chunk], ep | RSCAN_FLAG_INCL | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_base = excl;
+  }
+  __syncthreads();
+  off += (unsigned)s_base;
+#pragma unroll
+  for (unsigned i = 0; i < RSCAN_PER; i++) {
+    const unsigned r = r0 + i;
+    if (r < R) {
+      out_prefix[r] = off;
+      out16[r] = (uint16_t)v[i];
+      if (MODE == 0) n_cnt32[r] = 0u;
+    }
+    off += v[i];
+  }
+  if (chunk == n_chunks - 1 && tid == RSCAN_THREADS - 1) {  // (the last thread of the last chunk holds the grand total)
+    out_prefix[R] = off;
+    if (MODE == 1) res->n_pos_len = off;
+  }
 }
 
 // N position deltas (second half of replaceAndEncodeNs) + optional N -> A write-back

@@ -648,10 +648,35 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
   const unsigned len_blocks = (unsigned)min((size_t)(R + 15) / 16, (size_t)4096);  // four records per wave
   const bool fused = fused_k1(ctx);
   FQ_SPAN_BEGIN("records");
-  if (fused) {  // lengths from the record table alone; K1 counts the N's (the raw block is read once less)
-    hipLaunchKernelGGL(k_readlens, dim3((unsigned)min((size_t)(R + 255) / 256, (size_t)2048)), dim3(256), 0, st, b->recs, R, b->readlens,
-                       n_cnt32, lens32, b->result);
-    if ((rc = fq_scan_u32_to_u32(st, lens32, R, rec_start, lane.scan_tmp))) return rc;
+  // k_record_scan's look-back words: zero when (re)allocated, then epochs and tickets count on from launch to launch
+  const unsigned rscan_chunks = (R + RSCAN_CHUNK - 1) / RSCAN_CHUNK;
+  auto rscan_launch = [&](int mode) -> int {
+    const size_t need = (size_t)rscan_chunks * 8 + 16;
+    if (need > lane.rscan.cap) {
+      int rr = lane.rscan.reserve(need);
+      if (rr) return rr;
+      FQ_HIP(hipMemsetAsync(lane.rscan.p, 0, lane.rscan.cap, st));
+      lane.rscan_tickets = 0;
+    }
+    lane.rscan_epoch = (lane.rscan_epoch + 1u) & 0xFFFFFFu;
+    if (lane.rscan_epoch == 0u) {  // (every 16 M launches: words of the previous round of epochs must not be taken for new ones)
+      FQ_HIP(hipMemsetAsync(lane.rscan.p, 0, lane.rscan.cap, st));
+      lane.rscan_tickets = 0;
+      lane.rscan_epoch = 1u;
+    }
+    unsigned *ticket = lane.rscan.as<unsigned>();
+    unsigned long long *status = reinterpret_cast<unsigned long long *>(lane.rscan.as<uint8_t>() + 16);
+    if (mode == 0)
+      hipLaunchKernelGGL(k_record_scan<0>, dim3(rscan_chunks), dim3(RSCAN_THREADS), 0, st, b->recs, n_cnt32, R, b->readlens, rec_start, status, ticket,
+                         lane.rscan_tickets, lane.rscan_epoch, b->result);
+    else
+      hipLaunchKernelGGL(k_record_scan<1>, dim3(rscan_chunks), dim3(RSCAN_THREADS), 0, st, b->recs, n_cnt32, R, b->n_count, lane.n_off.as<uint32_t>(), status, ticket,
+                         lane.rscan_tickets, lane.rscan_epoch, b->result);
+    lane.rscan_tickets += rscan_chunks;
+    return FQGPU_OK;
+  };
+  if (fused) {  // lengths from the record table alone, scanned in the same launch; K1 counts the N's (the raw block is read once less)
+    if ((rc = rscan_launch(0))) return rc;
   } else {
     hipLaunchKernelGGL(k_readlens_ncount, dim3(len_blocks), dim3(256), 0, st, b->raw, b->recs, R,
                        b->readlens, b->n_count, n_cnt32, lens32, b->result);
@@ -681,10 +706,8 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
 
   // after both streams: the optional in-place N -> A must not race with their reads of raw
   FQ_SPAN_BEGIN("npos");
-  if (fused) {  // K1 left the N counts: 16-bit copy for the caller, offsets of the position deltas
-    hipLaunchKernelGGL(k_ncount16, dim3((unsigned)min((size_t)(R + 255) / 256, (size_t)2048)), dim3(256), 0, st, n_cnt32, R, b->n_count);
-    if ((rc = fq_scan_u32_to_u32(st, n_cnt32, R, lane.n_off.as<uint32_t>(), lane.scan_tmp))) return rc;
-    hipLaunchKernelGGL(k_store_npos_len, dim3(1), dim3(1), 0, st, lane.n_off.as<uint32_t>(), R, b->result);
+  if (fused) {  // K1 left the N counts: 16-bit copy for the caller, offsets of the position deltas, their total -- one launch
+    if ((rc = rscan_launch(1))) return rc;
   }
   hipLaunchKernelGGL(k_npos, dim3(rec_blocks), dim3(256), 0, st, b->raw, b->recs, R,
                      lane.n_off.as<uint32_t>(), b->n_pos, (flags & FQGPU_F_WRITE_BACK_N) ? 1 : 0);

@@ -143,6 +143,8 @@ struct EncLane {
   DevBuf n_cnt32;     // u32 [R] N count | u32 [R] length
   DevBuf n_off;       // u32 [R+1]
   DevBuf first_sym;   // u8 [R] sequence | u8 [R] quality: every record's first symbol in encode order (fused K1 -> K3)
+  DevBuf rscan;       // k_record_scan: u32 ticket, pad | u64 status[chunks] (zero when allocated; epochs and tickets count on)
+  unsigned rscan_epoch = 0, rscan_tickets = 0;  // launches so far (24 bits used) / tickets handed out so far
   DevBuf scan_tmp;
   EncScratch enc[2];
 };
