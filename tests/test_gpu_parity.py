@@ -1122,3 +1122,7 @@ def test_soak_sample_random_sizes_kinds_tables_parameters_and_call_paths():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_roundtrip.py"), "40", "424242"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "soak: 40 cases" in r.stdout
+    # ... and two cases with blocks of 64 to 96 MiB (round 3's sample stopped at 3 MiB)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_roundtrip.py"), "2", "515151", "96", "64"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "soak: 2 cases" in r.stdout

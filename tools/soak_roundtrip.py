@@ -6,7 +6,7 @@ the oracle's -> decode of the ORACLE's streams -> raw block byte-equal.  A third
 segment lengths and group sizes off their defaults, a third code a decode index and decode through it; the block goes
 through the device-resident calls, the host-pointer call or, unparsed, through the GPU's record finder; behind the
 host-pointer calls the oracle's streams are damaged (bit flips, truncation, random bytes) and decoded by both.
-    python tools/soak_roundtrip.py [cases, default 60] [first seed] [largest block in MiB, default 3]"""
+    python tools/soak_roundtrip.py [cases, default 60] [first seed] [largest block in MiB, default 3] [smallest block in MiB, default: 3000 bytes]"""
 import os
 import sys
 import time
@@ -85,6 +85,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     max_bytes = (int(sys.argv[3]) if len(sys.argv) > 3 else 3) << 20
+    min_bytes = (int(sys.argv[4]) << 20) if len(sys.argv) > 4 else 3000
     t0 = time.time()
     done = damaged = 0
     verbose = bool(os.environ.get("SOAK_VERBOSE"))
@@ -102,8 +103,8 @@ def main():
             done += several_blocks_in_flight(case, seed0 + case) > 0
             continue
         rng = np.random.default_rng(seed0 + case)
-        mode = int(rng.choice([2, 2, 3, 4, 4, 5]))
-        size = int(rng.integers(3000, max_bytes))
+        mode = int(rng.choice([2, 2, 3, 4, 4, 5, 6]))
+        size = int(rng.integers(min_bytes, max_bytes))
         raw, _ = F.synth_fastq(size, mode, seed=seed0 + case)
         recs = F.parse_fastq(raw)
         how = int(rng.integers(0, 4))
