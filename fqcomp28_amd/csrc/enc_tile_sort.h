@@ -296,7 +296,7 @@ k_tile_partition(const void *__restrict__ ckey_v, const uint8_t *__restrict__ cs
       const uint16_t *kb = reinterpret_cast<const uint16_t *>(kb4[j % NBUF]);
       const uint8_t *sbb = reinterpret_cast<const uint8_t *>(sb8[j % NBUF]);
       uint16_t *gpos = lpos16 + e0 + j * TS_BATCH;
-      const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
+      const unsigned nb = fq_uniform(min(TS_BATCH, nt - j * TS_BATCH));  // (wave-uniform by construction; said so, the loop below runs on a scalar counter: tests/test_build_invariants.py)
       constexpr unsigned G = 4;  // (four iterations in flight: eight cost 22 more VGPRs for the whole kernel, which every tile pays)
       for (unsigned cb = 0; cb < nb; cb += 64 * G) {  // wave-uniform trip count, branch-free, as below
         unsigned key[G], pos[G], head_of[G], sy[G];
@@ -333,7 +333,7 @@ k_tile_partition(const void *__restrict__ ckey_v, const uint8_t *__restrict__ cs
       }
     } else if (wave == 0 && j < nbatch) {
       uint16_t *kb = reinterpret_cast<uint16_t *>(kb4[j % NBUF]);
-      const unsigned nb = min(TS_BATCH, nt - j * TS_BATCH);
+      const unsigned nb = fq_uniform(min(TS_BATCH, nt - j * TS_BATCH));  // (see above)
       // Wave-uniform trip count with the bound checked inside: with a per-lane trip count the
       // compiler's unrolling lets low lanes run ahead of high lanes by a whole group of iterations,
       // and the rank is only right if iteration k of every lane precedes iteration k + 1 of any lane.
