@@ -766,6 +766,7 @@ def main():
             "config": {"workload": "%s (uniform ACGT, Phred~N(34,5) clipped [2,41]), -R %d blocks, tables from the first %d MiB, "
                                    "inputs resident in HBM" % (cfg_name, block_mib, args.sample_mib),
                        "layout": layout, "job_blocks": job_blocks, "blocks_this_gpu": len(blocks),
+                       "encode_lanes": ("%d blocks in flight per GPU" % args.lanes) if args.lanes else "library default: four blocks in flight per GPU, six for blocks below 48 M symbols",
                        "records_this_gpu": n_recs, "bases_this_gpu": n_bases,
                        "parallelism": ("block b -> rank b mod %d" % world if layout == "strong" else "every rank its own blocks (%d ranks)" % world)
                                       + ", one process per GPU, tables broadcast over gloo, no data-path collective, no RCCL"},
