@@ -76,6 +76,9 @@ _PROTOS = {
     "fqgpu_encode_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "fqgpu_encode_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fqgpu_encode_cancel": (C.c_int, [C.c_void_p]),
+    "fqgpu_encode_headers_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint, C.c_void_p, C.c_size_t]),
+    "fqgpu_encode_headers_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "fqgpu_encode_headers_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "fqgpu_encode_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                    C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -417,9 +420,13 @@ class Context:
         return dict(rc=rc, seq=bufs["seq"][:sl].copy(), qual=bufs["qual"][:ql].copy(), readlens=bufs["readlens"],
                     n_count=bufs["n_count"], n_pos=bufs["n_pos"][:nn].copy(), raw_after=raw)
 
-    def encode_raw(self, raw, flags=0, recs=None):
+    def encode_raw(self, raw, flags=0, recs=None, header_format=None):
         """The two-halves call on an UNPARSED chunk (fqgpu_encode_begin / _records / _wait / _end): the
-        record table comes back from the GPU.  -> dict like encode_block's, plus recs and used_len."""
+        record table comes back from the GPU.  -> dict like encode_block's, plus recs and used_len.
+        header_format = (types, separators, first_header) -- types[i] 0 = NUMERIC / 1 = STRING, separators as bytes,
+        first_header with its '@' -- also codes the header fields on the device (fqgpu_encode_headers_*):
+        `header_fields` = [(flags, content, lengths) per field] or, for a header that cannot be coded,
+        `headers_rc` = FQGPU_E_HEADER and `bad_record`."""
         raw = np.array(raw, dtype=np.uint8, copy=True)
         n, nb, used = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         if recs is not None:
@@ -428,10 +435,38 @@ class Context:
                                       0 if recs is None else len(recs), flags, C.byref(n), C.byref(nb), C.byref(used))
         if rc:
             return dict(rc=rc)
+        hdr = {}
+        if header_format is not None:
+            types, seps, first = header_format
+            types = np.ascontiguousarray(types, dtype=np.uint8)
+            first = np.frombuffer(bytes(first), dtype=np.uint8)
+            rc = lib().fqgpu_encode_headers_begin(self.h, _p(types), bytes(seps), len(types), _p(first), first.size)
+            if rc:
+                lib().fqgpu_encode_cancel(self.h)
+                return dict(rc=rc)
         table = np.zeros(n.value, dtype=REC_DTYPE)
         rc = lib().fqgpu_encode_records(self.h, _p(table), len(table))
         if rc:
             return dict(rc=rc)
+        if header_format is not None:
+            sizes = np.zeros((len(types), 3), dtype=np.uint32)
+            total, bad = C.c_size_t(0), C.c_size_t(0)
+            rc = lib().fqgpu_encode_headers_wait(self.h, _p(sizes), C.byref(total), C.byref(bad))
+            hdr["headers_rc"] = rc
+            if rc:
+                hdr["bad_record"] = bad.value
+            else:
+                out = np.zeros(max(total.value, 1), dtype=np.uint8)
+                _check(lib().fqgpu_encode_headers_end(self.h, _p(out), out.size), "fqgpu_encode_headers_end")
+                fields, at = [], 0
+                for f in range(len(types)):
+                    parts = []
+                    for k in range(3):
+                        parts.append(out[at:at + int(sizes[f, k])].copy())
+                        at += int(sizes[f, k])
+                    fields.append(tuple(parts))
+                assert at == total.value
+                hdr["header_fields"] = fields
         sl, ql, nn = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         rc = lib().fqgpu_encode_wait(self.h, C.byref(sl), C.byref(ql), C.byref(nn))
         if rc:
@@ -441,7 +476,7 @@ class Context:
         rc = lib().fqgpu_encode_end(self.h, _p(raw), _p(seq), seq.size, C.byref(sl), _p(qual), qual.size, C.byref(ql),
                                     _p(readlens), _p(n_count), _p(n_pos), n_pos.size, C.byref(nn))
         return dict(rc=rc, seq=seq, qual=qual, readlens=readlens, n_count=n_count, n_pos=n_pos, raw_after=raw,
-                    recs=table, used_len=used.value, n_bases=nb.value)
+                    recs=table, used_len=used.value, n_bases=nb.value, **hdr)
 
     def decode_block(self, seq, qual, n_count, n_pos, recs, raw_skeleton):
         out = np.array(raw_skeleton, dtype=np.uint8, copy=True)

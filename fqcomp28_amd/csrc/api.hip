@@ -45,6 +45,7 @@ extern "C" const char *fqgpu_strerror(int code) {
   case FQGPU_E_NO_DEVICE: return "no usable MI355X / HIP device (there is no CPU fallback)";
   case FQGPU_E_NOMEM: return "out of device or host memory";
   case FQGPU_E_HIP: return g_hip_msg[0] ? g_hip_msg : "HIP runtime error";
+  case FQGPU_E_HEADER: return "read header the field coder cannot code (numeric field not an int32 / string field of 255 or more bytes)";
   default: return "unknown fqgpu error";
   }
 }
@@ -501,6 +502,7 @@ extern "C" void fqgpu_ctx_destroy(fqgpu_ctx *ctx) {
   DevBuf *bufs[] = {&ctx->n_cnt32, &ctx->n_off, &ctx->scan_tmp, &ctx->dec_desc, &ctx->dec_chunks, &ctx->dec_recstart};
   for (DevBuf *b : bufs) b->release();
   ctx->hp_parse.release();  // the device parser's scratch (fqgpu_ctx_reserve / fqgpu_encode_begin without a record table)
+  ctx->hp_hdr.release();
   for (int i = 0; i < FQ_MAX_LANES; i++) free_lane(ctx->lanes[i]);
   if (ctx->hp_block) fqgpu_dblock_destroy(ctx->hp_block);
   if (ctx->hp_ev_h2d) (void)hipEventDestroy(ctx->hp_ev_h2d);
@@ -993,6 +995,7 @@ static int hp_encode_begin(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, c
   int rc = use_device(ctx->device);
   if (rc) return rc;
   ctx->hp_pending = false;  // (a block begun and never collected is dropped: fqgpu_sync below waits for it)
+  ctx->hp_hdr.pending = ctx->hp_hdr.collected = false;
   size_t n_bases = 0, n_n = 0, used = raw_len;
   if (recs && (rc = check_recs(recs, n_recs, raw_len, &n_bases))) return rc;
   if ((rc = fqgpu_sync(ctx))) return rc;
@@ -1024,6 +1027,7 @@ static int hp_encode_begin(fqgpu_ctx *ctx, const uint8_t *raw, size_t raw_len, c
   ctx->hp_pending = true;
   ctx->hp_flags = flags;
   ctx->hp_done = st;
+  ctx->hp_used = used;
   if (n_recs_out) *n_recs_out = n_recs;
   if (n_bases_out) *n_bases_out = n_bases;
   if (used_len) *used_len = used;
@@ -1075,7 +1079,58 @@ extern "C" int fqgpu_encode_cancel(fqgpu_ctx *ctx) {
   int rc = use_device(ctx->device);
   if (rc) return rc;
   ctx->hp_pending = false;
+  ctx->hp_hdr.pending = ctx->hp_hdr.collected = false;
   return fqgpu_sync(ctx);
+}
+
+// The header fields of the block in flight (headers.hip), on the handle's copy stream -- where the chunk arrived and
+// its record table was uploaded or built -- beside the lane's encode kernels.
+extern "C" int fqgpu_encode_headers_begin(fqgpu_ctx *ctx, const uint8_t *field_types, const char *separators, unsigned n_fields,
+                                          const uint8_t *first_header, size_t first_header_len) {
+  if (!ctx || !ctx->hp_pending || !ctx->hp_block || ctx->hp_hdr.pending || !field_types || !first_header || (n_fields > 1 && !separators))
+    return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  const fqgpu_dblock *b = ctx->hp_block;
+  if ((rc = fq_headers_launch(ctx->stream, b->raw, ctx->hp_used, b->recs, b->n_recs, b->n_bases, field_types, separators, n_fields,
+                              first_header, first_header_len, ctx->hp_hdr)))
+    return rc == FQGPU_E_ARG ? rc : hp_fail(ctx, rc);
+  ctx->hp_hdr.pending = true;
+  ctx->hp_hdr.collected = false;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_encode_headers_wait(fqgpu_ctx *ctx, fqgpu_field_sizes *sizes, size_t *total_bytes, size_t *bad_record) {
+  if (!ctx || !ctx->hp_hdr.pending) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  HdrScratch &hs = ctx->hp_hdr;
+  if (!hs.collected) {
+    FQ_HIP_HP(hipStreamSynchronize(ctx->stream));
+    hs.collected = true;
+  }
+  const HdrResult &r = *hs.host_res;
+  if (r.first_error != ~0ull) {
+    if (bad_record) *bad_record = (size_t)(r.first_error >> 8);
+    return FQGPU_E_HEADER;
+  }
+  if (r.total > hs.bound) return hp_fail(ctx, FQGPU_E_HIP);  // (cannot happen: the bound covers every header byte once)
+  for (unsigned i = 0; sizes && i < hs.n_fields; i++) sizes[i] = {r.size[3 * i], r.size[3 * i + 1], r.size[3 * i + 2]};
+  if (total_bytes) *total_bytes = (size_t)r.total;
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_encode_headers_end(fqgpu_ctx *ctx, uint8_t *out, size_t out_cap) {
+  if (!ctx || !ctx->hp_hdr.pending || !out) return FQGPU_E_ARG;
+  size_t total = 0;
+  int rc = fqgpu_encode_headers_wait(ctx, nullptr, &total, nullptr);
+  if (rc) return rc;
+  if (out_cap < total) return FQGPU_E_ARG;
+  HdrScratch &hs = ctx->hp_hdr;
+  FQ_HIP_HP(hipMemcpyAsync(out, hs.out.p, total, hipMemcpyDeviceToHost, ctx->stream));
+  FQ_HIP_HP(hipStreamSynchronize(ctx->stream));
+  hs.pending = hs.collected = false;
+  return FQGPU_OK;
 }
 
 extern "C" int fqgpu_encode_end(fqgpu_ctx *ctx, uint8_t *raw, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,

@@ -110,6 +110,29 @@ struct ParseScratch {
   void release() { for (DevBuf *b : {&cnt, &base, &sum, &nl_pos, &scan_tmp}) b->release(); total_nl = 0; }
 };
 
+// Result words of the device header coder (headers.hip), and its grow-only scratch
+struct HdrResult {
+  unsigned long long first_error;  // record << 8 | code (1: numeric field, 2: string field too long) of the first header that cannot be coded; ~0: none
+  unsigned long long total;        // bytes of the output buffer in use
+  unsigned long long off[3 * FQGPU_HDR_MAX_FIELDS];  // per field: flags, content, lengths
+  uint32_t size[3 * FQGPU_HDR_MAX_FIELDS];
+};
+struct HdrScratch {
+  DevBuf wg_sum, wg_base, out, first, res;
+  HdrResult *host_res = nullptr;  // page-locked
+  uint8_t *host_first = nullptr;  // page-locked staging of the dataset's first header
+  unsigned n_fields = 0;
+  size_t bound = 0;
+  bool pending = false;           // kernels queued for the block in flight, results not collected yet
+  bool collected = false;
+  void release() {
+    for (DevBuf *b : {&wg_sum, &wg_base, &out, &first, &res}) b->release();
+    if (host_res) (void)hipHostFree(host_res);
+    if (host_first) (void)hipHostFree(host_first);
+    host_res = nullptr; host_first = nullptr; pending = collected = false;
+  }
+};
+
 // Scratch of the encode pipeline for one stream.
 struct EncScratch {
   DevBuf slot_of;     // u32 [M]   sorted position of every symbol (encode order)
@@ -183,6 +206,8 @@ struct fqgpu_ctx {
   bool hp_pending = false;            // a block of fqgpu_encode_begin is in flight (fqgpu_encode_end collects it)
   unsigned hp_flags = 0;
   hipStream_t hp_done = nullptr;      // the stream its last kernel runs on
+  size_t hp_used = 0;                 // bytes of the chunk up to its last complete record
+  HdrScratch hp_hdr;                  // fqgpu_encode_headers_*: the header fields of the block in flight
 };
 
 EncLane *fq_next_lane(fqgpu_ctx *ctx, size_t n_bases);  // api.hip: round-robin, creates streams on first use
@@ -258,6 +283,10 @@ int fq_wipe_launch(fqgpu_ctx *ctx, fqgpu_dblock *b);
 int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_rec *recs_dev, size_t n_recs, size_t n_bases,
                           uint32_t *counts_dev, uint32_t *err_dev);
 int fq_parse_count(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, ParseScratch &ps, size_t *n_recs);
+size_t fq_headers_bound(size_t raw_len, size_t n_recs, size_t n_bases, unsigned n_fields);
+int fq_headers_launch(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, const fqgpu_rec *recs_dev, size_t n_recs, size_t n_bases,
+                      const uint8_t *field_types, const char *separators, unsigned n_fields, const uint8_t *first_header,
+                      size_t first_header_len, HdrScratch &hs);
 int fq_parse_records(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, ParseScratch &ps, fqgpu_rec *recs_dev,
                      size_t n_recs, size_t *n_bases, size_t *n_n, size_t *used_len);
 

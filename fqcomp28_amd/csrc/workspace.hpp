@@ -281,6 +281,7 @@ protected:
     fqgpuCheck(fqgpu_ctx_create(device, meta->ft_seq.get(), meta->ft_qual.get(), &ctx_), "Workspace");
     // one block at a time per workspace (like the reference's): one encode lane, a quarter of the scratch
     fqgpuCheck(fqgpu_ctx_set_lanes(ctx_, 1), "Workspace");
+    for (const auto t : fmt_.field_types) field_types_.push_back(t == headers::FieldType::STRING ? 1 : 0);
   }
   /** every chunk codes its first header against the dataset's first header (src/workspace.cpp:90-93) */
   void startNewChunk() { prev_header_fields_ = first_header_fields_; }
@@ -291,6 +292,7 @@ protected:
   const headers::HeaderFormatSpeciciation fmt_;
   const headers::header_fields_t first_header_fields_;
   headers::header_fields_t prev_header_fields_;
+  std::vector<uint8_t> field_types_;  // fmt_.field_types as the C ABI takes them (0 = NUMERIC, 1 = STRING)
   fqgpu_ctx *ctx_ = nullptr;
 };
 
@@ -306,8 +308,9 @@ public:
 
   /** Encodes reads into cbs, allocating memory in cbs as needed; mutates the chunk (N -> A).
    *  The chunk may come UNPARSED (records empty, as FastqReader hands it out): the GPU then finds the
-   *  records, and chunk.records / the length sums are filled in from its table.  The GPU work is
-   *  started first; the headers are coded on this thread while it runs. */
+   *  records, and chunk.records / the length sums are filled in from its table.  The header fields are coded on
+   *  the GPU as well (fqgpu_encode_headers_*: round 3 coded them on this thread, 78 ms per 256 MiB chunk beside
+   *  3 ms of GPU work); FQGPU_SHIM_HOST_HEADERS=1 keeps the host coder (headers.hpp), same bytes. */
   void encodeChunk(FastqChunk &chunk, CompressedBuffersDst &cbs) {
     StageClock clk;
     cbs.clear();
@@ -329,6 +332,11 @@ public:
       bool armed = true;
       ~InFlight() { if (armed) (void)fqgpu_encode_cancel(ctx); }
     } in_flight{ctx_};
+    static const bool host_headers = std::getenv("FQGPU_SHIM_HOST_HEADERS") != nullptr;
+    if (!host_headers)
+      fqgpuCheck(fqgpu_encode_headers_begin(ctx_, field_types_.data(), fmt_.separators.data(), static_cast<unsigned>(fmt_.n_fields()),
+                                            reinterpret_cast<const uint8_t *>(meta_->first_header.data()), meta_->first_header.size()),
+                 "encodeChunk");
     clk.lap("begin");
     if (!parsed) {
       recs.resize(R);
@@ -337,12 +345,35 @@ public:
       recordViews(chunk, recs);
     }
     clk.lap("records");
-    // ---- host work in the shadow of the GPU: the header fields
+    // ---- the header fields
     cbs.header_fields.resize(fmt_.n_fields());
     cbs.original_size.header_fields.resize(fmt_.n_fields());
     for (auto &field : cbs.header_fields) field.clear();
-    startNewChunk();
-    for (const FastqRecord &r : chunk.records) headers::encodeHeader(r.header(), fmt_, prev_header_fields_, cbs.header_fields);
+    bool on_host = host_headers;
+    if (!on_host) {
+      std::vector<fqgpu_field_sizes> sizes(fmt_.n_fields());
+      std::size_t total = 0, bad = 0;
+      const int rc = fqgpu_encode_headers_wait(ctx_, sizes.data(), &total, &bad);
+      if (rc == FQGPU_E_HEADER) {
+        on_host = true;  // the host coder throws the reference-side exception for that header (below)
+      } else {
+        fqgpuCheck(rc, "encodeChunk");
+        header_stage_.resize(total);
+        fqgpuCheck(fqgpu_encode_headers_end(ctx_, reinterpret_cast<uint8_t *>(header_stage_.data()), header_stage_.size()), "encodeChunk");
+        const std::byte *at = header_stage_.data();
+        for (std::size_t i = 0; i < fmt_.n_fields(); ++i) {
+          auto &f = cbs.header_fields[i];
+          f.isDifferentFlag.assign(at, at + sizes[i].isDifferentFlag); at += sizes[i].isDifferentFlag;
+          f.content.assign(at, at + sizes[i].content); at += sizes[i].content;
+          f.contentLength.assign(at, at + sizes[i].contentLength); at += sizes[i].contentLength;
+        }
+      }
+    }
+    if (on_host) {
+      startNewChunk();
+      for (const FastqRecord &r : chunk.records) headers::encodeHeader(r.header(), fmt_, prev_header_fields_, cbs.header_fields);
+      if (!host_headers) throw std::logic_error("encodeChunk: the device refused a header the host coder takes");
+    }
     clk.lap("headers");
     // ---- the streams, at their exact sizes
     std::size_t seq_len = 0, qual_len = 0, n_pos_len = 0;
@@ -369,6 +400,10 @@ public:
     clk.done(chunk.idx);
   }
 
+private:
+  stream_bytes_t header_stage_;  // page-locked landing place of the header field streams
+
+public:
   /** The misc pass (the reference's compressMiscBuffers, src/workspace.cpp:176-213): readlens, n_count,
    *  n_pos and every header field stream through memcompress, original sizes recorded for the container */
   void compressMiscBuffers(CompressedBuffersDst &cbs) const { compressMiscBuffers(cbs, fmt_); }

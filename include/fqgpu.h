@@ -45,7 +45,9 @@ enum {
                             * neither A, C, G, T nor N (base2bits_arr holds UINT_MAX there, src/fse_sequence.cpp:6-14), bad table */
   FQGPU_E_NO_DEVICE = -5,  /* no usable GPU / HIP runtime error: the product path has no CPU fallback */
   FQGPU_E_NOMEM = -6,
-  FQGPU_E_HIP = -7
+  FQGPU_E_HIP = -7,
+  FQGPU_E_HEADER = -8      /* a read header the field coder cannot code: a NUMERIC field without digits or outside int32, a
+                            * changing STRING field of 255 or more bytes (asserts in the reference: src/headers.cpp:20,83,117) */
 };
 
 /* FastqRecord reduced to what this path needs (src/defs.h:22-32): byte offsets
@@ -163,6 +165,29 @@ int fqgpu_encode_cancel(fqgpu_ctx *ctx);
 int fqgpu_encode_end(fqgpu_ctx *ctx, uint8_t *raw, uint8_t *seq_out, size_t seq_cap, size_t *seq_len,
                      uint8_t *qual_out, size_t qual_cap, size_t *qual_len, uint16_t *readlens_out,
                      uint16_t *n_count_out, uint16_t *n_pos_out, size_t n_pos_cap, size_t *n_pos_len);
+
+/* ---- header fields of the block in flight, coded on the device (replaces the per-record calls of
+ * CompressionWorkspace::encodeHeader, src/workspace.cpp:95-126, over FieldStorageDst::storeString /
+ * storeNumeric, src/headers.cpp:76-91, 110-120).  The chunk is on the device already and every field is
+ * coded against the SAME field of the header in front, which is input: all records at once.
+ * Between fqgpu_encode_begin and fqgpu_encode_end / _cancel, in any order with _records / _wait:
+ *   fqgpu_encode_headers_begin  field_types[i]: 0 = NUMERIC, 1 = STRING (headers::FieldType, src/headers.h:12);
+ *                               separators[i] behind field i (n_fields - 1 of them): HeaderFormatSpeciciation,
+ *                               src/headers.h:28-41; first_header: the dataset's first header, '@' included,
+ *                               against which the chunk's first header is coded (Workspace::startNewChunk,
+ *                               src/workspace.cpp:90-93).  Queues the work and returns.
+ *   fqgpu_encode_headers_wait   sizes[i] = FieldStorage sizes of field i; *total_bytes = their sum.
+ *                               FQGPU_E_HEADER: *bad_record = the first record whose header cannot be coded
+ *   fqgpu_encode_headers_end    out: per field, in order, isDifferentFlag | content | contentLength, the bytes
+ *                               the reference's FieldStorageDst holds after the chunk's last header */
+#define FQGPU_HDR_MAX_FIELDS 64
+typedef struct {
+  uint32_t isDifferentFlag, content, contentLength;  /* = FieldStorage::sizes, src/headers.h:60-64 */
+} fqgpu_field_sizes;
+int fqgpu_encode_headers_begin(fqgpu_ctx *ctx, const uint8_t *field_types, const char *separators, unsigned n_fields,
+                               const uint8_t *first_header, size_t first_header_len);
+int fqgpu_encode_headers_wait(fqgpu_ctx *ctx, fqgpu_field_sizes *sizes, size_t *total_bytes, size_t *bad_record);
+int fqgpu_encode_headers_end(fqgpu_ctx *ctx, uint8_t *out, size_t out_cap);
 
 /* ---- block decode (replaces the second pass of
  * DecompressionWorkspace::decodeChunk, src/workspace.cpp:84-87:

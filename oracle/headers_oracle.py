@@ -13,9 +13,23 @@ small.  Follows, function by function:
 Pinned by the reference's own known answers (test/headers_test.cpp:12-33: the two example headers)
 and its round-trip properties; the reference asserts no stream bytes anywhere.
 """
+import re
 import struct
 
 NUMERIC, STRING = "N", "S"
+_FROM_CHARS = re.compile(rb"-?[0-9]+")
+
+
+def parse_numeric(val: bytes) -> int:
+    """std::from_chars(first, last, int32) as the reference uses it (src/headers.cpp:19, 116): an optional '-',
+    digits up to the first other character; no digit or outside int32 = the reference's assert (ValueError here)"""
+    m = _FROM_CHARS.match(val)
+    if not m:
+        raise ValueError("not a number: %r" % val)
+    v = int(m.group())
+    if not -2**31 <= v < 2**31:
+        raise ValueError("outside int32: %r" % val)
+    return v
 
 
 def _isalnum(c):  # std::isalnum in the "C" locale
@@ -64,14 +78,14 @@ class FieldStreams:
             self.flags.append(0)
             return prev
         self.flags.append(1)
-        assert len(val) < 255
+        if len(val) >= 255:  # FIELDLEN_MAX: the reference's assert (src/headers.cpp:83)
+            raise ValueError("field of 255 or more bytes")
         self.content += val
         self.lengths.append(len(val))
         return val
 
     def store_numeric(self, val: bytes, prev: int) -> int:
-        v = int(val)
-        assert -2**31 <= v < 2**31
+        v = parse_numeric(val)
         self.content += struct.pack("<I", (v - prev) & 0xFFFFFFFF)
         return v
 
@@ -80,7 +94,7 @@ def encode_headers(headers, first_header=None):
     """-> (types, seps, [FieldStreams per field]) for the headers of one chunk"""
     first_header = headers[0] if first_header is None else first_header
     types, seps = format_from_header(first_header)
-    prev = [int(f) if t == NUMERIC else f for f, t in zip(split_header(first_header, seps), types)]
+    prev = [parse_numeric(f) if t == NUMERIC else f for f, t in zip(split_header(first_header, seps), types)]
     streams = [FieldStreams() for _ in types]
     for h in headers:
         for i, (f, t) in enumerate(zip(split_header(h, seps), types)):

@@ -1,7 +1,9 @@
 """End-to-end timing of the C++ block farm (tools/fqc_tool.cpp over fqcomp28_amd/csrc/process.hpp):
 writes a synthetic config-2 FASTQ file, compresses it with T worker threads, decompresses it, compares.
     python tools/farm_bench.py [MiB] [threads ...]
-The clock of fqc_tool covers the worker threads only (tables and handles are built before)."""
+The clock of fqc_tool covers the worker threads only (tables and handles are built before).
+FARM_COMPRESS_ONLY=1 skips the decompression and the comparison (A/B runs of the compressing side:
+FQGPU_SHIM_HOST_HEADERS=1 is passed on to the workers)."""
 import json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,8 +26,16 @@ with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
     for t in threads:
         arc, back = os.path.join(tmp, "a.fqc"), os.path.join(tmp, "back.fastq")
         t0 = time.time()
-        c = json.loads(subprocess.run([exe, "c", src, arc, "-t", str(t)], capture_output=True, text=True, check=True).stdout.splitlines()[-1])
+        run = subprocess.run([exe, "c", src, arc, "-t", str(t)], capture_output=True, text=True, check=True)
+        c = json.loads(run.stdout.splitlines()[-1])
         wall_c = time.time() - t0
+        if os.environ.get("FQGPU_SHIM_TRACE"):
+            print(run.stderr, flush=True)
+        if os.environ.get("FARM_COMPRESS_ONLY"):
+            print(json.dumps({"threads": t, "raw_MiB": size >> 20, "blocks": c["blocks"], "compress_workers_s": round(c["seconds"], 3),
+                              "compress_MBps": round(size / c["seconds"] / 1e6, 1), "compress_wall_s_incl_analysis_and_io": round(wall_c, 2),
+                              "archive_bytes": os.path.getsize(arc), "host_headers": bool(os.environ.get("FQGPU_SHIM_HOST_HEADERS"))}), flush=True)
+            continue
         t0 = time.time()
         d = json.loads(subprocess.run([exe, "d", arc, back, "-t", str(t)], capture_output=True, text=True, check=True).stdout.splitlines()[-1])
         wall_d = time.time() - t0
