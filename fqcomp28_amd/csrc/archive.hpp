@@ -172,21 +172,45 @@ public:
       if (data.size() > 0xFFFFFFFFull) throw std::length_error("writeBlock: a field of 4 GiB or more");
       bytes += (orig ? 8 : 4) + data.size();
     });
-    std::vector<uint8_t> image(bytes);
-    uint8_t *p = image.data();
-    blockfmt::put32(p, cb.original_size.total);
-    blockfmt::put32(p, cb.original_size.n_records);
-    blockfmt::blockFields(cb, fmt, [&](const uint32_t *orig, const auto &data) {
-      if (orig) blockfmt::put32(p, *orig);
-      blockfmt::put32(p, static_cast<uint32_t>(data.size()));
-      if (!data.empty()) std::memcpy(p, data.data(), data.size());
-      p += data.size();
-    });
     BlockRef ref;
     ref.offset = claim_.fetch_add(bytes);
     ref.end = ref.offset + bytes;
     ref.idx = cb.chunk_idx;
-    file_.writeAt(ref.offset, image.data(), bytes);
+    // The two FSE streams are nine tenths of a block: they go out from where they lie.  Everything else -- the size
+    // words, the side streams, the header fields -- is gathered into a small image in between (round 3 built ONE image
+    // of the whole block: 90 MB allocated, zeroed and copied per block, a third of the 34 ms a block's write took).
+    constexpr std::size_t DIRECT = 256u << 10;
+    std::vector<uint8_t> image;
+    image.reserve(bytes < (8u << 20) ? bytes : (8u << 20));
+    uint64_t at = ref.offset;
+    const auto flush = [&] {
+      if (image.empty()) return;
+      file_.writeAt(at, image.data(), image.size());
+      at += image.size();
+      image.clear();
+    };
+    const auto word = [&](uint32_t v) {
+      uint8_t b[4];
+      uint8_t *p = b;
+      blockfmt::put32(p, v);
+      image.insert(image.end(), b, b + 4);
+    };
+    word(cb.original_size.total);
+    word(cb.original_size.n_records);
+    blockfmt::blockFields(cb, fmt, [&](const uint32_t *orig, const auto &data) {
+      if (orig) word(*orig);
+      word(static_cast<uint32_t>(data.size()));
+      const auto *bytes_of = reinterpret_cast<const uint8_t *>(data.data());
+      if (data.size() >= DIRECT) {
+        flush();
+        file_.writeAt(at, bytes_of, data.size());
+        at += data.size();
+      } else if (!data.empty()) {
+        image.insert(image.end(), bytes_of, bytes_of + data.size());
+      }
+    });
+    flush();
+    if (at != ref.end) throw std::logic_error("writeBlock: the block's fields do not add up to its size");
     const std::lock_guard<std::mutex> guard(index_mutex_);
     index_.push_back(ref);
   }

@@ -15,8 +15,11 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <exception>
 #include <functional>
+#include <mutex>
 #include <thread>
 
 #include "archive.hpp"
@@ -33,6 +36,12 @@ struct Settings {  // the part of src/settings.h:36-50 this path needs, plus the
    *  from the end, so both forms decode everywhere).  Default: fresh tables per block -- the
    *  accumulation makes misc-stream work grow quadratically with the number of blocks. */
   bool accumulate_n_buffers = false;
+  /** Workers that may be inside the source (reading a chunk) at once; 0 = a quarter of the workers, at least two.
+   *  Sixteen workers that all read 256 MiB at the same moment share the host's memory bandwidth, finish together, then
+   *  share the PCIe link, then the page cache: every stage waits for the slowest of sixteen.  Through a gate the first
+   *  chunks are on the GPU while the others are still being read and the stages overlap from the first block on
+   *  (FQGPU_FARM_READ_GATE overrides; a value of n_threads or more = no gate). */
+  unsigned read_gate = 0;
 };
 
 struct InputStats {  // src/report.h
@@ -71,6 +80,32 @@ template <class Body, class OnFailure> void runWorkers(unsigned n, Body &&body, 
   for (auto &e : errors) if (e) std::rethrow_exception(e);
 }
 template <class Body> void runWorkers(unsigned n, Body &&body) { runWorkers(n, body, [] {}); }
+
+/** at most `slots` holders at a time (C++17: no std::counting_semaphore) */
+class Gate {
+public:
+  explicit Gate(unsigned slots) : free_(slots) {}
+  class Pass {
+  public:
+    explicit Pass(Gate &g) : g_(g) {
+      std::unique_lock<std::mutex> lock(g_.m_);
+      g_.cv_.wait(lock, [&] { return g_.free_ > 0; });
+      --g_.free_;
+    }
+    ~Pass() {
+      { const std::lock_guard<std::mutex> lock(g_.m_); ++g_.free_; }
+      g_.cv_.notify_one();
+    }
+    Pass(const Pass &) = delete;
+    Pass &operator=(const Pass &) = delete;
+  private:
+    Gate &g_;
+  };
+private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  unsigned free_;
+};
 }  // namespace detail
 
 /** The compression farm: `next_chunk(chunk)` and `write_block(cbs)` are called concurrently from
@@ -101,13 +136,19 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
   std::vector<CompressedStats> cstats(T);
   FarmReport rep;
   rep.blocks_per_worker.assign(T, 0);
+  unsigned gate_slots = set.read_gate ? set.read_gate : std::max(2u, T / 4);
+  if (const char *e = std::getenv("FQGPU_FARM_READ_GATE")) gate_slots = std::max(1, std::atoi(e));
+  detail::Gate read_gate(std::min(gate_slots, T));
   const auto t0 = std::chrono::steady_clock::now();
   detail::runWorkers(T, [&](unsigned t) {
     FastqChunk &chunk = chunks[t];
     CompressedBuffersDst &cbs = buffers[t];
     for (;;) {
       StageClock clk;
-      if (!next_chunk(chunk)) break;
+      {
+        const detail::Gate::Pass pass(read_gate);
+        if (!next_chunk(chunk)) break;
+      }
       clk.lap("read");
       if (!set.accumulate_n_buffers) { cbs.n_count.clear(); cbs.n_pos.clear(); }
       wksp[t]->encodeChunk(chunk, cbs);  // (an unparsed chunk has its records found on the GPU: the sums are known afterwards)
