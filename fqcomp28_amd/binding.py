@@ -85,6 +85,10 @@ _PROTOS = {
     "fqgpu_decode_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.c_size_t]),
+    "fqgpu_encode_index": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "fqgpu_decode_block_indexed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "fqgpu_dblock_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_void_p)]),
     "fqgpu_dblock_create_from_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -475,16 +479,32 @@ class Context:
         readlens, n_count, n_pos = np.zeros(n.value, np.uint16), np.zeros(n.value, np.uint16), np.zeros(nn.value, np.uint16)
         rc = lib().fqgpu_encode_end(self.h, _p(raw), _p(seq), seq.size, C.byref(sl), _p(qual), qual.size, C.byref(ql),
                                     _p(readlens), _p(n_count), _p(n_pos), n_pos.size, C.byref(nn))
+        if rc == 0 and (flags & F_DECODE_INDEX):
+            hdr["index"] = []
+            for s in (0, 1):
+                n_idx = C.c_size_t(0)
+                _check(lib().fqgpu_encode_index(self.h, s, None, 0, C.byref(n_idx)), "fqgpu_encode_index")
+                idx = np.zeros(n_idx.value, dtype=np.uint8)
+                _check(lib().fqgpu_encode_index(self.h, s, _p(idx) if idx.size else None, idx.size, C.byref(n_idx)), "fqgpu_encode_index")
+                hdr["index"].append(idx)
         return dict(rc=rc, seq=seq, qual=qual, readlens=readlens, n_count=n_count, n_pos=n_pos, raw_after=raw,
                     recs=table, used_len=used.value, n_bases=nb.value, **hdr)
 
-    def decode_block(self, seq, qual, n_count, n_pos, recs, raw_skeleton):
+    def decode_block(self, seq, qual, n_count, n_pos, recs, raw_skeleton, index=None):
+        """index = (sequence index, quality index) as encode_raw(flags=F_DECODE_INDEX) returns them:
+        fqgpu_decode_block_indexed, every stream decoded from all its snapshots at once"""
         out = np.array(raw_skeleton, dtype=np.uint8, copy=True)
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         qual = np.ascontiguousarray(qual, dtype=np.uint8)
         n_count = np.ascontiguousarray(n_count, dtype=np.uint16)
         n_pos = np.ascontiguousarray(n_pos, dtype=np.uint16)
         recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+        if index is not None:
+            si, qi = (np.ascontiguousarray(x, dtype=np.uint8) for x in index)
+            rc = lib().fqgpu_decode_block_indexed(self.h, _p(seq), seq.size, _p(qual), qual.size, _p(n_count), n_count.size,
+                                                  _p(n_pos), n_pos.size, _p(recs), len(recs), _p(out), out.size,
+                                                  _p(si) if si.size else None, si.size, _p(qi) if qi.size else None, qi.size)
+            return rc, out
         rc = lib().fqgpu_decode_block(self.h, _p(seq), seq.size, _p(qual), qual.size, _p(n_count), n_count.size,
                                       _p(n_pos), n_pos.size, _p(recs), len(recs), _p(out), out.size)
         return rc, out

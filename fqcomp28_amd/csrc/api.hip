@@ -569,11 +569,10 @@ extern "C" int fqgpu_dblock_fetch_index(fqgpu_ctx *ctx, const fqgpu_dblock *b, i
   return FQGPU_OK;
 }
 
-extern "C" int fqgpu_dblock_load_index(fqgpu_ctx *ctx, fqgpu_dblock *b, int stream, const void *data, size_t len) {
-  if (!ctx || !b || stream < 0 || stream > 1 || (!data && len)) return FQGPU_E_ARG;
-  int rc = fqgpu_sync(ctx);
-  if (rc) return rc;
-  if (len == 0) { b->index_bytes[stream] = 0; return FQGPU_OK; }
+// an index for this block's stream: its header must describe the block; room for it on the device.  (The decode checks
+// that every stride consumes exactly the bits between two snapshots; the states in a snapshot are taken as they are:
+// a container that stores an index protects it with a checksum -- archive.hpp's DecodeIndexFile does.)
+static int index_accept(fqgpu_dblock *b, int stream, const void *data, size_t len) {
   const unsigned B = stream ? FQGPU_QUAL_MODELS : FQGPU_SEQ_MODELS;
   FqIndexHeader h;
   if (len < sizeof(h)) return FQGPU_E_CORRUPT;
@@ -588,6 +587,15 @@ extern "C" int fqgpu_dblock_load_index(fqgpu_ctx *ctx, fqgpu_dblock *b, int stre
     b->index_cap[stream] = b->index[stream] ? len : 0;
     if (!b->index[stream]) return FQGPU_E_NOMEM;
   }
+  return FQGPU_OK;
+}
+
+extern "C" int fqgpu_dblock_load_index(fqgpu_ctx *ctx, fqgpu_dblock *b, int stream, const void *data, size_t len) {
+  if (!ctx || !b || stream < 0 || stream > 1 || (!data && len)) return FQGPU_E_ARG;
+  int rc = fqgpu_sync(ctx);
+  if (rc) return rc;
+  if (len == 0) { b->index_bytes[stream] = 0; return FQGPU_OK; }
+  if ((rc = index_accept(b, stream, data, len))) return rc;
   FQ_HIP(hipMemcpy(b->index[stream], data, len, hipMemcpyHostToDevice));
   b->index_bytes[stream] = len;
   return FQGPU_OK;
@@ -1179,6 +1187,22 @@ extern "C" int fqgpu_encode_end(fqgpu_ctx *ctx, uint8_t *raw, uint8_t *seq_out, 
   return FQGPU_OK;
 }
 
+// The decode index of the block fqgpu_encode_begin coded with FQGPU_F_DECODE_INDEX: after fqgpu_encode_wait or _end,
+// until the handle's next host-pointer call.
+extern "C" int fqgpu_encode_index(fqgpu_ctx *ctx, int stream, uint8_t *out, size_t cap, size_t *len) {
+  if (!ctx || !ctx->hp_block || stream < 0 || stream > 1 || !len) return FQGPU_E_ARG;
+  const fqgpu_dblock *b = ctx->hp_block;
+  if (b->last_op != 1 || !b->result_pulled) return FQGPU_E_ARG;
+  *len = b->index_bytes[stream];
+  if (!out || !*len) return FQGPU_OK;
+  if (cap < *len) return FQGPU_E_ARG;
+  int rc = use_device(ctx->device);
+  if (rc) return rc;
+  FQ_HIP(hipMemcpyAsync(out, b->index[stream], *len, hipMemcpyDeviceToHost, ctx->hp_done));
+  FQ_HIP(hipStreamSynchronize(ctx->hp_done));
+  return FQGPU_OK;
+}
+
 // Host-pointer encode, one block per call, as asynchronous as one call can be: the inputs go up on
 // the handle's copy stream, the lane's kernels wait for that event (not for the host), the result
 // block lands in page-locked memory behind the last kernel, and the streams come down with their
@@ -1203,10 +1227,9 @@ extern "C" int fqgpu_encode_block(fqgpu_ctx *ctx, uint8_t *raw, size_t raw_len, 
                           n_pos_cap, n_pos_len);
 }
 
-extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual,
-                                  size_t qual_len, const uint16_t *n_count, size_t n_count_len,
-                                  const uint16_t *n_pos, size_t n_pos_len, const fqgpu_rec *recs,
-                                  size_t n_recs, uint8_t *raw_out, size_t raw_len) {
+static int hp_decode(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual, size_t qual_len, const uint16_t *n_count,
+                     size_t n_count_len, const uint16_t *n_pos, size_t n_pos_len, const fqgpu_rec *recs, size_t n_recs, uint8_t *raw_out,
+                     size_t raw_len, const uint8_t *const index[2], const size_t index_len[2]) {
   if (!ctx || !seq || !qual || !n_count || !recs || !raw_out || !seq_len || !qual_len) return FQGPU_E_ARG;
   if (n_count_len < n_recs) return FQGPU_E_CORRUPT;
   int rc = use_device(ctx->device);
@@ -1230,6 +1253,12 @@ extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq
   // the reference pops from the END of n_count (src/fse_sequence.cpp:115-126)
   FQ_HIP_HP(hipMemcpyAsync(b->n_count, n_count + (n_count_len - n_recs), n_recs * 2, hipMemcpyHostToDevice, st));
   if (n_pos_len) FQ_HIP_HP(hipMemcpyAsync(b->n_pos, n_pos, n_pos_len * 2, hipMemcpyHostToDevice, st));
+  for (int s = 0; s < 2; s++)  // (hp_block_acquire has dropped whatever index the staging block held)
+    if (index[s] && index_len[s]) {
+      if ((rc = index_accept(b, s, index[s], index_len[s]))) return hp_fail(ctx, rc);
+      FQ_HIP_HP(hipMemcpyAsync(b->index[s], index[s], index_len[s], hipMemcpyHostToDevice, st));
+      b->index_bytes[s] = index_len[s];
+    }
   b->seq_len = seq_len; b->qual_len = qual_len; b->n_pos_len = n_pos_len;
   b->last_op = 2;
   b->result_pulled = false;
@@ -1249,4 +1278,25 @@ extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq
   if (b->host_result.s[0].bad_symbol || b->host_result.s[1].bad_symbol) return FQGPU_E_ARG;
   if (b->host_result.s[0].corrupt || b->host_result.s[1].corrupt) return FQGPU_E_CORRUPT;
   return FQGPU_OK;
+}
+
+extern "C" int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual,
+                                  size_t qual_len, const uint16_t *n_count, size_t n_count_len,
+                                  const uint16_t *n_pos, size_t n_pos_len, const fqgpu_rec *recs,
+                                  size_t n_recs, uint8_t *raw_out, size_t raw_len) {
+  const uint8_t *const index[2] = {nullptr, nullptr};
+  const size_t index_len[2] = {0, 0};
+  return hp_decode(ctx, seq, seq_len, qual, qual_len, n_count, n_count_len, n_pos, n_pos_len, recs, n_recs, raw_out, raw_len, index, index_len);
+}
+
+// The same with the decode index the block's encode left (FQGPU_F_DECODE_INDEX, fqgpu_encode_index): each stream is
+// decoded from every snapshot at once instead of by one lane from its end.
+extern "C" int fqgpu_decode_block_indexed(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual, size_t qual_len,
+                                          const uint16_t *n_count, size_t n_count_len, const uint16_t *n_pos, size_t n_pos_len,
+                                          const fqgpu_rec *recs, size_t n_recs, uint8_t *raw_out, size_t raw_len,
+                                          const uint8_t *seq_index, size_t seq_index_len, const uint8_t *qual_index, size_t qual_index_len) {
+  if ((seq_index_len && !seq_index) || (qual_index_len && !qual_index)) return FQGPU_E_ARG;
+  const uint8_t *const index[2] = {seq_index, qual_index};
+  const size_t index_len[2] = {seq_index_len, qual_index_len};
+  return hp_decode(ctx, seq, seq_len, qual, qual_len, n_count, n_count_len, n_pos, n_pos_len, recs, n_recs, raw_out, raw_len, index, index_len);
 }

@@ -457,6 +457,118 @@ private:
   bool done_ = false;
 };
 
+/** The decode indexes of an archive's blocks, in a file of their own beside it (`<archive>.fqx`): an extension the
+ *  reference knows nothing of, so the .fqc file stays exactly what the reference reads and writes, and an archive
+ *  without the file decodes at the format's own pace.  A block's entry is found by the position of its chunk in the
+ *  input (CompressedBuffers::chunk_idx), and is only handed out if its checksum holds: the decoder takes the states
+ *  in a snapshot as they are (api.hip: index_accept).
+ *    "FQX1" | entries as they were claimed: { u32 chunk_idx, u32 0, u64 seq bytes, u64 qual bytes, u64 fnv1a-64 of the
+ *    two indexes } seq index | qual index ... | table: n x { u64 offset of the entry } | u64 n | "FQX1" */
+class DecodeIndexFile {
+public:
+  static path_t pathFor(const path_t &archive_path) { return path_t(archive_path.string() + ".fqx"); }
+  static constexpr uint32_t MAGIC = 0x31585146u;  // "FQX1"
+  static constexpr std::size_t HEAD = 32;
+
+  /** to write (Create) or to read an existing one */
+  DecodeIndexFile(const path_t &p, PosFile::Mode m) : file_(p, m) {
+    if (m == PosFile::Mode::Create) {
+      file_.writeAt(0, &MAGIC, 4);
+      claim_.store(4);
+      return;
+    }
+    const uint64_t size = file_.size();
+    uint32_t magic = 0;
+    uint64_t n = 0;
+    if (size < 16) throw std::runtime_error("decode index file: too short");
+    file_.readAt(0, &magic, 4);
+    if (magic != MAGIC) throw std::runtime_error("decode index file: not one");
+    file_.readAt(size - 4, &magic, 4);
+    file_.readAt(size - 12, &n, 8);
+    if (magic != MAGIC || n > (size - 16) / 8) throw std::runtime_error("decode index file: damaged trailer (was it closed?)");
+    std::vector<uint64_t> offsets(n);
+    end_of_entries_ = size - 12 - 8 * n;
+    if (n) file_.readAt(end_of_entries_, offsets.data(), 8 * n);
+    at_.assign(n, 0);
+    for (const uint64_t off : offsets) {
+      if (end_of_entries_ < 4 + HEAD || off < 4 || off > end_of_entries_ - HEAD) throw std::runtime_error("decode index file: entry outside the file");
+      uint32_t idx = 0;
+      file_.readAt(off, &idx, 4);
+      if (idx >= n) throw std::runtime_error("decode index file: entry of a chunk the file cannot hold");
+      at_[idx] = off;
+    }
+  }
+
+  /** Thread-safe; concurrent callers write concurrently. */
+  void put(const CompressedBuffers &cb) {
+    const auto &s = cb.decode_index[0], &q = cb.decode_index[1];
+    uint8_t head[HEAD];
+    const uint32_t idx = cb.chunk_idx, zero = 0;
+    const uint64_t ns = s.size(), nq = q.size(), sum = checksum(s, q);
+    std::memcpy(head, &idx, 4); std::memcpy(head + 4, &zero, 4);
+    std::memcpy(head + 8, &ns, 8); std::memcpy(head + 16, &nq, 8); std::memcpy(head + 24, &sum, 8);
+    const uint64_t off = claim_.fetch_add(HEAD + ns + nq);
+    file_.writeAt(off, head, HEAD);
+    if (ns) file_.writeAt(off + HEAD, s.data(), ns);
+    if (nq) file_.writeAt(off + HEAD + ns, q.data(), nq);
+    const std::lock_guard<std::mutex> guard(m_);
+    offsets_.push_back(off);
+  }
+  /** after the last put: the table and the trailer */
+  void close() {
+    const uint64_t n = offsets_.size(), at = claim_.load();
+    if (n) file_.writeAt(at, offsets_.data(), 8 * n);
+    file_.writeAt(at + 8 * n, &n, 8);
+    file_.writeAt(at + 8 * n + 8, &MAGIC, 4);
+  }
+
+  /** the indexes of chunk cb.chunk_idx into cb.decode_index; false: the file has none for it.  Thread-safe. */
+  bool get(CompressedBuffers &cb) const {
+    cb.decode_index[0].clear(); cb.decode_index[1].clear();
+    if (cb.chunk_idx >= at_.size() || at_[cb.chunk_idx] == 0) return false;
+    const uint64_t off = at_[cb.chunk_idx];
+    uint8_t head[HEAD];
+    file_.readAt(off, head, HEAD);
+    uint32_t idx = 0;
+    uint64_t ns = 0, nq = 0, sum = 0;
+    std::memcpy(&idx, head, 4); std::memcpy(&ns, head + 8, 8); std::memcpy(&nq, head + 16, 8); std::memcpy(&sum, head + 24, 8);
+    if (idx != cb.chunk_idx || ns > end_of_entries_ || nq > end_of_entries_ || off + HEAD + ns + nq > end_of_entries_)
+      throw std::runtime_error("decode index file: damaged entry of chunk " + std::to_string(cb.chunk_idx));
+    cb.decode_index[0].resize(ns);
+    cb.decode_index[1].resize(nq);
+    if (ns) file_.readAt(off + HEAD, cb.decode_index[0].data(), ns);
+    if (nq) file_.readAt(off + HEAD + ns, cb.decode_index[1].data(), nq);
+    if (checksum(cb.decode_index[0], cb.decode_index[1]) != sum)
+      throw std::runtime_error("decode index file: checksum of chunk " + std::to_string(cb.chunk_idx) + " does not hold");
+    return true;
+  }
+
+private:
+  static uint64_t checksum(const std::vector<std::byte> &a, const std::vector<std::byte> &b) {
+    // FNV-1a over 8-byte words (the indexes are u16 / u64 tables: a multiple of 8 bytes up to a short tail)
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (const auto *v : {&a, &b}) {
+      const std::size_t n = v->size();
+      const auto *p = reinterpret_cast<const uint8_t *>(v->data());
+      std::size_t i = 0;
+      for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+      }
+      for (; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+      h = (h ^ n) * 0x100000001b3ull;
+    }
+    return h;
+  }
+  PosFile file_;
+  std::atomic<uint64_t> claim_{0};
+  std::mutex m_;
+  std::vector<uint64_t> offsets_;   // writing: entries so far
+  std::vector<uint64_t> at_;        // reading: entry of chunk idx (0 = none: offset 0 holds the magic)
+  uint64_t end_of_entries_ = 0;
+};
+
 /** Dataset analysis (src/prepare.cpp:42-47): the tables of the first sample_size_bytes of the file, on the GPU */
 inline DatasetMeta analyzeDataset(const path_t &fastq_file, std::size_t sample_size_bytes, int device = 0) {
   FastqChunk chunk;

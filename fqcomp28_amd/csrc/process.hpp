@@ -42,6 +42,9 @@ struct Settings {  // the part of src/settings.h:36-50 this path needs, plus the
    *  chunks are on the GPU while the others are still being read and the stages overlap from the first block on
    *  (FQGPU_FARM_READ_GATE overrides; a value of n_threads or more = no gate). */
   unsigned read_gate = 0;
+  /** Extension: compress also writes `<archive>.fqx`, the decode indexes of every block (archive.hpp: DecodeIndexFile;
+   *  about 2 % of the archive's size); decompress uses the file whenever it lies beside the archive. */
+  bool decode_index = false;
 };
 
 struct InputStats {  // src/report.h
@@ -128,6 +131,7 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
   detail::runWorkers(T, [&](unsigned t) {
     wksp[t] = std::make_unique<CompressionWorkspace>(&meta, set.devices[t % set.devices.size()]);
     wksp[t]->reserve(set.reading_chunk_size);
+    wksp[t]->setDecodeIndex(set.decode_index);
     chunks[t].raw_data.reserve(set.reading_chunk_size);
     buffers[t].seq.reserve(set.reading_chunk_size / 8 + (1u << 20));
     buffers[t].qual.reserve(set.reading_chunk_size / 3 + (1u << 20));
@@ -181,11 +185,18 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
 inline FarmReport processReads(const path_t &mates1, const path_t &archive_path, const Settings &set) {
   Archive archive(archive_path, mates1, set.sample_chunk_size, set.devices.at(0));
   FastqReader reader(mates1, set.reading_chunk_size);
+  std::unique_ptr<DecodeIndexFile> sidecar;
+  if (set.decode_index) sidecar = std::make_unique<DecodeIndexFile>(DecodeIndexFile::pathFor(archive_path), PosFile::Mode::Create);
   FarmReport rep = compressFarm(
       archive.meta(), [&](FastqChunk &c) { return reader.readNextChunk(c); },
-      [&](const CompressedBuffersDst &cbs) { archive.writeBlock(cbs); }, [&] { reader.abort(); }, set);
+      [&](const CompressedBuffersDst &cbs) {
+        archive.writeBlock(cbs);
+        if (sidecar) sidecar->put(cbs);
+      },
+      [&] { reader.abort(); }, set);
   archive.writeIndex();
   archive.flush();
+  if (sidecar) sidecar->close();
   return rep;
 }
 
@@ -204,12 +215,18 @@ FarmReport decompressFarm(const DatasetMeta &meta, Source &&next_block, Sink &&w
   detail::runWorkers(T, [&](unsigned t) {
     CompressedBuffersSrc cbs;
     FastqChunk chunk;
-    while (next_block(cbs)) {
+    for (;;) {
+      StageClock clk;
+      if (!next_block(cbs)) break;
+      clk.lap("read");
       wksp[t]->decodeChunk(chunk, cbs);
+      clk.lap("decodeChunk");
       istats[t].raw += chunk.raw_data.size();
       istats[t].n_records += chunk.records.size();
       rep.blocks_per_worker[t]++;
       write_chunk(chunk);
+      clk.lap("write");
+      clk.done(chunk.idx);
     }
   }, stop);
   rep.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -226,8 +243,16 @@ FarmReport decompressFarm(const DatasetMeta &meta, Source &&next_block, Sink &&w
 inline FarmReport processArchiveParts(const path_t &archive_path, const path_t &mates1_out, const Settings &set) {
   Archive archive(archive_path);
   FastqWriter writer(mates1_out, archive.chunkOffsets());
+  std::unique_ptr<DecodeIndexFile> sidecar;
+  if (std::filesystem::exists(DecodeIndexFile::pathFor(archive_path)))
+    sidecar = std::make_unique<DecodeIndexFile>(DecodeIndexFile::pathFor(archive_path), PosFile::Mode::Read);
   FarmReport rep = decompressFarm(
-      archive.meta(), [&](CompressedBuffersSrc &cbs) { return archive.readBlock(cbs); },
+      archive.meta(),
+      [&](CompressedBuffersSrc &cbs) {
+        if (!archive.readBlock(cbs)) return false;
+        if (sidecar) (void)sidecar->get(cbs);  // (a chunk the file has no entry for is decoded without)
+        return true;
+      },
       [&](const FastqChunk &chunk) { writer.writeChunk(chunk); }, [&] { archive.abort(); }, set);
   writer.flush();
   return rep;

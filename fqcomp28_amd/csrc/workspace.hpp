@@ -112,9 +112,14 @@ struct CompressedBuffers {  // src/compressed_buffers.h:34-69
   std::vector<std::byte> n_pos, compressed_n_pos;
   cb_original_sizes_t original_size;
   uint32_t chunk_idx = 0;
+  /** Extension, not in the reference and not in the .fqc container: the decode index of the sequence / quality
+   *  stream (fqgpu_encode_index), filled by encodeChunk when the workspace was asked for it, used by decodeChunk
+   *  when present.  The farm keeps it in a file beside the archive (archive.hpp: DecodeIndexFile). */
+  std::vector<std::byte> decode_index[2];
   /* like the reference, clear() does NOT clear n_count / n_pos */
   virtual void clear() {
     seq.clear(); qual.clear();
+    decode_index[0].clear(); decode_index[1].clear();
     readlens.clear(); compressed_readlens.clear();
     for (auto &chf : compressed_header_fields) chf.clear();
     original_size.clear();
@@ -306,6 +311,10 @@ public:
     if (chunk_bytes) fqgpuCheck(fqgpu_ctx_reserve(ctx_, chunk_bytes, chunk_bytes / 64 + 1, chunk_bytes / 2 + 1), "reserve");
   }
 
+  /** encodeChunk also leaves cbs.decode_index (extension: a decoder that has it decodes a stream from every
+   *  snapshot at once; seq / qual and everything else in cbs are unchanged) */
+  void setDecodeIndex(bool on) { decode_index_ = on; }
+
   /** Encodes reads into cbs, allocating memory in cbs as needed; mutates the chunk (N -> A).
    *  The chunk may come UNPARSED (records empty, as FastqReader hands it out): the GPU then finds the
    *  records, and chunk.records / the length sums are filled in from its table.  The header fields are coded on
@@ -321,7 +330,7 @@ public:
     if (parsed) recs = DatasetMeta::toRecordTable(chunk);
     std::size_t R = 0, n_bases = 0, used = 0;
     fqgpuCheck(fqgpu_encode_begin(ctx_, raw, chunk.raw_data.size(), parsed ? recs.data() : nullptr, recs.size(),
-                                  FQGPU_F_WRITE_BACK_N, &R, &n_bases, &used),
+                                  FQGPU_F_WRITE_BACK_N | (decode_index_ ? FQGPU_F_DECODE_INDEX : 0u), &R, &n_bases, &used),
                "encodeChunk");
     // From here to fqgpu_encode_end the block is in flight: copies of chunk.raw_data and of `recs` may still be queued.
     // Whatever throws in between (a chunk that ends inside a record, the header coder, a failing call) must not
@@ -392,6 +401,12 @@ public:
                                 reinterpret_cast<uint16_t *>(cbs.n_pos.data() + pos_at), n_pos_len, &n_pos_len),
                "encodeChunk");
     in_flight.armed = false;
+    for (int s = 0; s < 2 && decode_index_; ++s) {
+      std::size_t n = 0;
+      fqgpuCheck(fqgpu_encode_index(ctx_, s, nullptr, 0, &n), "encodeChunk");
+      cbs.decode_index[s].resize(n);
+      fqgpuCheck(fqgpu_encode_index(ctx_, s, reinterpret_cast<uint8_t *>(cbs.decode_index[s].data()), n, &n), "encodeChunk");
+    }
     clk.lap("end");
     cbs.original_size.n_records = static_cast<uint32_t>(R);
     cbs.original_size.total = static_cast<uint32_t>(chunk.raw_data.size());
@@ -402,6 +417,7 @@ public:
 
 private:
   stream_bytes_t header_stage_;  // page-locked landing place of the header field streams
+  bool decode_index_ = false;
 
 public:
   /** The misc pass (the reference's compressMiscBuffers, src/workspace.cpp:176-213): readlens, n_count,
@@ -448,12 +464,18 @@ public:
    *  (headers decoded on the host, lengths from readlens, '+' and newlines), the second fills the
    *  sequence and quality lines on the GPU */
   void decodeChunk(FastqChunk &chunk, CompressedBuffersSrc &cbs) {
+    StageClock clk;
     chunk.clear();  // prepareFastqChunk (src/workspace.h:127-133)
     chunk.idx = cbs.chunk_idx;
+    // (chunks of one archive differ by a record or two: room for the next ones, or every slightly longer chunk costs a
+    // fresh page-locked block -- 45 ms of hipHostMalloc for 256 MiB)
+    if (chunk.raw_data.capacity() < cbs.original_size.total) chunk.raw_data.reserve(cbs.original_size.total + cbs.original_size.total / 16 + 4096);
     chunk.raw_data.resize(cbs.original_size.total);
     chunk.records.resize(cbs.original_size.n_records);
     startNewChunk();
+    clk.lap("resize");
     decompressMiscBuffers(cbs);
+    clk.lap("misc");
     if (cbs.header_fields.size() != fmt_.n_fields()) throw std::invalid_argument("decodeChunk: header field streams do not match the format");
     if (cbs.readlens.size() < chunk.records.size() * sizeof(readlen_t)) throw std::invalid_argument("decodeChunk: readlens too short");
     char *dst = chunk.raw_data.data();
@@ -472,15 +494,23 @@ public:
       chunk.tot_reads_length += r.length;
       chunk.headers_length += r.header_length;
     }
+    clk.lap("headers+layout");
     RecordTable recs = DatasetMeta::toRecordTable(chunk);
-    fqgpuCheck(fqgpu_decode_block(ctx_, reinterpret_cast<const uint8_t *>(cbs.seq.data()), cbs.seq.size(),
-                                  reinterpret_cast<const uint8_t *>(cbs.qual.data()), cbs.qual.size(),
-                                  reinterpret_cast<const uint16_t *>(cbs.n_count.data()),
-                                  cbs.index.n_count / sizeof(uint16_t),
-                                  reinterpret_cast<const uint16_t *>(cbs.n_pos.data()),
-                                  cbs.index.n_pos / sizeof(uint16_t), recs.data(), recs.size(),
-                                  reinterpret_cast<uint8_t *>(chunk.raw_data.data()), chunk.raw_data.size()),
+    clk.lap("table");
+    // (with cbs.decode_index -- an extension, empty in a reference archive -- every stream is decoded from all its
+    // snapshots at once; without, by one lane from its end: the format's own pace)
+    fqgpuCheck(fqgpu_decode_block_indexed(ctx_, reinterpret_cast<const uint8_t *>(cbs.seq.data()), cbs.seq.size(),
+                                          reinterpret_cast<const uint8_t *>(cbs.qual.data()), cbs.qual.size(),
+                                          reinterpret_cast<const uint16_t *>(cbs.n_count.data()),
+                                          cbs.index.n_count / sizeof(uint16_t),
+                                          reinterpret_cast<const uint16_t *>(cbs.n_pos.data()),
+                                          cbs.index.n_pos / sizeof(uint16_t), recs.data(), recs.size(),
+                                          reinterpret_cast<uint8_t *>(chunk.raw_data.data()), chunk.raw_data.size(),
+                                          reinterpret_cast<const uint8_t *>(cbs.decode_index[0].data()), cbs.decode_index[0].size(),
+                                          reinterpret_cast<const uint8_t *>(cbs.decode_index[1].data()), cbs.decode_index[1].size()),
                "decodeChunk");
+    clk.lap("gpu");
+    clk.done(chunk.idx);
   }
 
   /** The misc pass backwards (the reference's decompressMiscBuffers, src/workspace.cpp:215-256): every

@@ -199,6 +199,17 @@ int fqgpu_decode_block(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const
                        size_t qual_len, const uint16_t *n_count, size_t n_count_len,
                        const uint16_t *n_pos, size_t n_pos_len, const fqgpu_rec *recs,
                        size_t n_recs, uint8_t *raw_out, size_t raw_len);
+/* Extension (nothing in the reference): the same decode with the sidecar the block's encode left when it ran with
+ * FQGPU_F_DECODE_INDEX -- fqgpu_encode_index(stream 0 / 1) after fqgpu_encode_wait or _end hands it out, *len alone
+ * when out is NULL.  The streams are unchanged; with its index a stream is decoded from every snapshot (one per
+ * Mi symbols) at once instead of by one lane from its end.  An index that does not describe the block, or between
+ * whose snapshots the strides do not consume exactly the stream's bits, is FQGPU_E_CORRUPT (the states inside a
+ * snapshot are taken as they are: store an index under a checksum); length 0 = no index for that stream. */
+int fqgpu_encode_index(fqgpu_ctx *ctx, int stream, uint8_t *out, size_t cap, size_t *len);
+int fqgpu_decode_block_indexed(fqgpu_ctx *ctx, const uint8_t *seq, size_t seq_len, const uint8_t *qual, size_t qual_len,
+                               const uint16_t *n_count, size_t n_count_len, const uint16_t *n_pos, size_t n_pos_len,
+                               const fqgpu_rec *recs, size_t n_recs, uint8_t *raw_out, size_t raw_len,
+                               const uint8_t *seq_index, size_t seq_index_len, const uint8_t *qual_index, size_t qual_index_len);
 
 /* ---- device-resident block farm ---------------------------------------
  * Blocks stay in HBM: a "dblock" owns device copies of one raw block, its

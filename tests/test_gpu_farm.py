@@ -156,6 +156,75 @@ def test_a_damaged_block_ends_the_farm_with_an_error_not_a_hang(F, tool, tmp_pat
         assert not os.path.exists(tmp_path / "bad.fastq") and not os.path.exists(str(tmp_path / "bad.fastq") + ".part")
 
 
+def test_cpp_farm_with_decode_indexes_beside_the_archive(F, tool, tmp_path):
+    """`c --index` (extension): the archive's blocks are what they are without it, `<archive>.fqx` holds every block's
+    decode indexes, `d` uses the file when it lies there -- a damaged one ends the command (checksum), without one the
+    archive decodes at the format's own pace"""
+    raw, _ = F.synth_fastq(44 << 20, 4, seed=17)
+    src = tmp_path / "in.fastq"
+    raw.tofile(src)
+    plain, arc = tmp_path / "plain.fqc", tmp_path / "indexed.fqc"
+    run_tool(tool, "c", src, plain, "-t", 3, "-R", 8, "-S", 4)
+    assert not os.path.exists(str(plain) + ".fqx")
+    rep = run_tool(tool, "c", src, arc, "-t", 3, "-R", 8, "-S", 4, "--index")
+    side = str(arc) + ".fqx"
+    assert os.path.getsize(side) > 64 * rep["blocks"]
+    a, b = A.read_archive(str(plain)), A.read_archive(str(arc))
+    assert a[:3] == b[:3] and len(a[3]) == len(b[3]) == rep["blocks"] >= 5
+    for x, y in zip(a[3], b[3]):   # blocks sorted by chunk: the same fields, byte for byte
+        assert (x.idx, x.total, x.n_records, x.seq, x.qual, x.readlens, x.n_count, x.n_pos, x.fields) == \
+               (y.idx, y.total, y.n_records, y.seq, y.qual, y.readlens, y.n_count, y.n_pos, y.fields)
+    back = tmp_path / "back.fastq"
+    run_tool(tool, "d", arc, back, "-t", 3)
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+    os.remove(back)
+    # a bit inside an index, a file without its trailer: the command fails, nothing is left behind
+    data = bytearray(open(side, "rb").read())
+    for what, bad in (("bit", bytes(data[:4000]) + bytes([data[4000] ^ 4]) + bytes(data[4001:])), ("cut", bytes(data[:-20]))):
+        open(side, "wb").write(bad)
+        r = subprocess.run([tool, "d", str(arc), str(back), "-t", "3"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "decode index file" in r.stderr, (what, r.stdout, r.stderr)
+        assert not os.path.exists(back) and not os.path.exists(str(back) + ".part")
+    os.remove(side)
+    run_tool(tool, "d", arc, back, "-t", 3)
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+
+
+def test_indexed_decode_through_the_host_pointer_calls(F):
+    """fqgpu_encode_begin(FQGPU_F_DECODE_INDEX) .. fqgpu_encode_index, then fqgpu_decode_block_indexed: the streams are
+    the oracle's with or without the index, the indexed decode restores the block from the ORACLE's streams, an index
+    of another block is refused, one index alone is enough for its stream"""
+    raw, _ = F.synth_fastq(20 << 20, 4, seed=19)
+    recs = F.parse_fastq(raw)
+    _, _, sft, qft = O.freq_tables(raw, recs)
+    e = O.OracleCtx(sft, qft).encode(raw, recs)
+    ctx = F.Context(sft, qft)
+    ctx.set_index_stride(1 << 20)
+    g = ctx.encode_raw(raw, flags=F.F_DECODE_INDEX)
+    assert g["rc"] == 0 and all(np.array_equal(g[k], e[k]) for k in ("seq", "qual", "n_count", "n_pos"))
+    si, qi = g["index"]
+    n_sym = int(recs["len"].sum())
+    assert si.size == 32 + ((n_sym - 1) >> 20) * (16 + 2 * 256) and qi.size == 32 + ((n_sym - 1) >> 20) * (16 + 2 * 8192)
+    skeleton = O.blank_skeleton(raw, recs)
+    for index in ((si, qi), (si, np.zeros(0, np.uint8)), (np.zeros(0, np.uint8), qi)):
+        rc, out = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, skeleton, index=index)
+        assert rc == 0 and np.array_equal(out, raw)
+    # an index made for another block (fewer symbols): refused as corrupt, and the handle works afterwards
+    half = F.parse_fastq(raw[: raw.size // 2])
+    end = int(half[-1]["qual_off"] + half[-1]["len"] + 1)
+    g2 = ctx.encode_raw(raw[:end], flags=2)
+    rc, _ = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, skeleton, index=g2["index"])
+    assert rc == -3   # FQGPU_E_CORRUPT
+    # a snapshot's bit position damaged: the stride does not end where the next snapshot says
+    bad = qi.copy()
+    bad[32 + 2] ^= 1
+    rc, _ = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, skeleton, index=(si, bad))
+    assert rc == -3
+    rc, out = ctx.decode_block(e["seq"], e["qual"], e["n_count"], e["n_pos"], recs, skeleton)
+    assert rc == 0 and np.array_equal(out, raw)
+    ctx.close()
+
+
 def test_encode_from_an_unparsed_chunk_through_the_c_abi(F):
     """fqgpu_encode_begin without a record table (the GPU finds the records), _records, _wait, _end:
     the table is the host parser's, the streams are the oracle's, a partial record at the end of

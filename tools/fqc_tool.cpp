@@ -13,7 +13,7 @@ using namespace fqcomp28;
 
 int main(int argc, char **argv) {
   if (argc < 4 || (strcmp(argv[1], "c") && strcmp(argv[1], "d"))) {
-    std::fprintf(stderr, "usage: fqc_tool c|d <in> <out> [-t N] [-R MiB] [-S MiB] [-d 0,1,..] [--accumulate-n]\n");
+    std::fprintf(stderr, "usage: fqc_tool c|d <in> <out> [-t N] [-R MiB] [-S MiB] [-d 0,1,..] [--accumulate-n] [--index]\n");
     return 2;
   }
   Settings set;
@@ -24,6 +24,7 @@ int main(int argc, char **argv) {
     else if (a == "-R") set.reading_chunk_size = (std::size_t)std::atoll(val()) << 20;
     else if (a == "-S") set.sample_chunk_size = (std::size_t)std::atoll(val()) << 20;
     else if (a == "--accumulate-n") set.accumulate_n_buffers = true;
+    else if (a == "--index") set.decode_index = true;
     else if (a == "-d") {
       set.devices.clear();
       for (const char *p = val(); *p;) { set.devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
