@@ -1119,10 +1119,10 @@ extern "C" int fqgpu_encode_headers_wait(fqgpu_ctx *ctx, fqgpu_field_sizes *size
   }
   const HdrResult &r = *hs.host_res;
   if (r.first_error != ~0ull) {
+    if ((r.first_error & 0xFFu) == 3u || r.total > hs.bound) return FQGPU_E_ARG;  // a record table whose headers overlap: not this chunk's
     if (bad_record) *bad_record = (size_t)(r.first_error >> 8);
     return FQGPU_E_HEADER;
   }
-  if (r.total > hs.bound) return hp_fail(ctx, FQGPU_E_HIP);  // (cannot happen: the bound covers every header byte once)
   for (unsigned i = 0; sizes && i < hs.n_fields; i++) sizes[i] = {r.size[3 * i], r.size[3 * i + 1], r.size[3 * i + 2]};
   if (total_bytes) *total_bytes = (size_t)r.total;
   return FQGPU_OK;

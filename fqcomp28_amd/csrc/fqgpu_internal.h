@@ -112,7 +112,8 @@ struct ParseScratch {
 
 // Result words of the device header coder (headers.hip), and its grow-only scratch
 struct HdrResult {
-  unsigned long long first_error;  // record << 8 | code (1: numeric field, 2: string field too long) of the first header that cannot be coded; ~0: none
+  unsigned long long first_error;  // record << 8 | code (1: numeric field, 2: string field too long, 3: the streams would not fit -- a record
+                                   // table that is not this chunk's) of the first header that cannot be coded; ~0: none
   unsigned long long total;        // bytes of the output buffer in use
   unsigned long long off[3 * FQGPU_HDR_MAX_FIELDS];  // per field: flags, content, lengths
   uint32_t size[3 * FQGPU_HDR_MAX_FIELDS];

@@ -80,20 +80,24 @@ __device__ __forceinline__ void hdr_texts(const uint8_t *raw, const fqgpu_rec *r
                                           unsigned first_len, HdrText &cur, HdrText &prev) {
   cur.s = cur.end = prev.s = prev.end = raw;
   if (r >= R) return;
+  // (offsets are clamped so that a caller's table that does not describe the chunk -- records out of order, a sequence
+  // at offset 0 -- yields nonsense fields, never an address outside the block: seq_off and qual_off + len are inside it)
   const fqgpu_rec me = recs[r];
   unsigned line = 0;
   if (r) {
     const fqgpu_rec before = recs[r - 1];
     const unsigned line0 = r > 1 ? recs[r - 2].qual_off + recs[r - 2].len + 1u : 0u;
     line = before.qual_off + before.len + 1u;
-    prev.end = raw + (before.seq_off - 1u);
-    prev.s = min(raw + line0 + 1u, prev.end);
+    const unsigned end0 = before.seq_off ? before.seq_off - 1u : 0u;
+    prev.end = raw + end0;
+    prev.s = raw + min(line0 + 1u, end0);
   } else {
     prev.end = first_hdr + first_len;
     prev.s = first_hdr + min(1u, first_len);
   }
-  cur.end = raw + (me.seq_off - 1u);
-  cur.s = min(raw + line + 1u, cur.end);  // behind the '@'
+  const unsigned end1 = me.seq_off ? me.seq_off - 1u : 0u;
+  cur.end = raw + end1;
+  cur.s = raw + min(line + 1u, end1);  // behind the '@'
 }
 
 // Field i of record r against the same field of the header in front.  STRING: returns count | bytes << 9 of what the
@@ -154,11 +158,13 @@ k_hdr_count(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs,
 // one workgroup: wave w takes the fields w, w + 4, ...; wg_base[wg][field] = {bytes, count} in front of the workgroup
 __global__ void __launch_bounds__(HDR_THREADS)
 k_hdr_layout(const uint32_t *__restrict__ wg_sum, unsigned n_wg, unsigned R, const HdrFormat fmt, uint2 *__restrict__ wg_base,
-             HdrResult *__restrict__ res) {
-  __shared__ unsigned tot_bytes[FQGPU_HDR_MAX_FIELDS], tot_cnt[FQGPU_HDR_MAX_FIELDS];
+             HdrResult *__restrict__ res, unsigned long long cap) {
+  __shared__ unsigned long long tot_bytes[FQGPU_HDR_MAX_FIELDS];  // (64 bits: a table that is not the chunk's can add up to anything)
+  __shared__ unsigned tot_cnt[FQGPU_HDR_MAX_FIELDS];
   const unsigned lane = fq_lane(), F = fmt.n_fields;
   for (unsigned i = threadIdx.x >> 6; i < F; i += HDR_WAVES) {
-    unsigned carry_b = 0, carry_c = 0;
+    unsigned long long carry_b = 0;
+    unsigned carry_c = 0;
     if (fmt.type[i])
       for (unsigned base = 0; base < n_wg; base += 64) {
         const unsigned w = base + lane;
@@ -170,7 +176,7 @@ k_hdr_layout(const uint32_t *__restrict__ wg_sum, unsigned n_wg, unsigned R, con
           const unsigned oc = __shfl_up(ic, d), ob = __shfl_up(ib, d);
           if (lane >= (unsigned)d) { ic += oc; ib += ob; }
         }
-        if (w < n_wg) wg_base[(size_t)w * F + i] = make_uint2(carry_b + ib - b, carry_c + ic - c);
+        if (w < n_wg) wg_base[(size_t)w * F + i] = make_uint2((unsigned)carry_b + ib - b, carry_c + ic - c);
         carry_b += __shfl(ib, 63);
         carry_c += __shfl(ic, 63);
       }
@@ -180,21 +186,24 @@ k_hdr_layout(const uint32_t *__restrict__ wg_sum, unsigned n_wg, unsigned R, con
   if (threadIdx.x == 0) {
     unsigned long long off = 0;
     for (unsigned i = 0; i < F; i++) {
-      const unsigned s_flags = fmt.type[i] ? R : 0u, s_content = fmt.type[i] ? tot_bytes[i] : 4u * R, s_len = fmt.type[i] ? tot_cnt[i] : 0u;
-      res->size[3 * i] = s_flags; res->size[3 * i + 1] = s_content; res->size[3 * i + 2] = s_len;
+      const unsigned long long s_flags = fmt.type[i] ? R : 0u, s_content = fmt.type[i] ? tot_bytes[i] : 4ull * R, s_len = fmt.type[i] ? tot_cnt[i] : 0u;
+      res->size[3 * i] = (uint32_t)s_flags; res->size[3 * i + 1] = (uint32_t)s_content; res->size[3 * i + 2] = (uint32_t)s_len;
       res->off[3 * i] = off; off += s_flags;
       res->off[3 * i + 1] = off; off += s_content;
       res->off[3 * i + 2] = off; off += s_len;
     }
     res->total = off;
+    // more than every header byte once: only a record table whose "headers" overlap can ask for that; nothing is written
+    if (off > cap) hdr_error(res, 0, 3);
   }
 }
 
 __global__ void __launch_bounds__(HDR_THREADS)
 k_hdr_write(const uint8_t *__restrict__ raw, const fqgpu_rec *__restrict__ recs, unsigned R, const uint8_t *__restrict__ first_hdr,
             unsigned first_len, const HdrFormat fmt, const uint2 *__restrict__ wg_base, HdrResult *__restrict__ res,
-            uint8_t *__restrict__ out) {
+            uint8_t *__restrict__ out, unsigned long long cap) {
   __shared__ unsigned wtot[FQGPU_HDR_MAX_FIELDS][HDR_WAVES];
+  if (res->total > cap) return;  // (uniform: written by k_hdr_layout)
   const unsigned r = blockIdx.x * HDR_THREADS + threadIdx.x, lane = fq_lane(), wave = threadIdx.x >> 6;
   const bool active = r < R;
   HdrText cur, prev;
@@ -272,9 +281,9 @@ int fq_headers_launch(hipStream_t st, const uint8_t *raw_dev, size_t raw_len, co
   hipLaunchKernelGGL(k_hdr_count, dim3(n_wg), dim3(HDR_THREADS), 0, st, raw_dev, recs_dev, (unsigned)n_recs, hs.first.as<uint8_t>(),
                      (unsigned)first_header_len, fmt, hs.wg_sum.as<uint32_t>(), res);
   hipLaunchKernelGGL(k_hdr_layout, dim3(1), dim3(HDR_THREADS), 0, st, hs.wg_sum.as<uint32_t>(), n_wg, (unsigned)n_recs, fmt,
-                     hs.wg_base.as<uint2>(), res);
+                     hs.wg_base.as<uint2>(), res, (unsigned long long)bound);
   hipLaunchKernelGGL(k_hdr_write, dim3(n_wg), dim3(HDR_THREADS), 0, st, raw_dev, recs_dev, (unsigned)n_recs, hs.first.as<uint8_t>(),
-                     (unsigned)first_header_len, fmt, hs.wg_base.as<uint2>(), res, hs.out.as<uint8_t>());
+                     (unsigned)first_header_len, fmt, hs.wg_base.as<uint2>(), res, hs.out.as<uint8_t>(), (unsigned long long)bound);
   FQ_HIP(hipGetLastError());
   FQ_HIP(hipMemcpyAsync(hs.host_res, res, sizeof(HdrResult), hipMemcpyDeviceToHost, st));
   hs.n_fields = n_fields;

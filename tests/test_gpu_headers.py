@@ -177,3 +177,19 @@ def test_headers_of_a_whole_synthetic_block(ctx, F):
     for k in ("seq", "qual", "readlens", "n_count", "n_pos"):
         assert np.array_equal(g[k], plain[k]), k
     ctx.close()
+
+
+def test_a_record_table_that_is_not_the_chunks_never_faults(ctx, golden_dir):
+    """the header coder takes header r from the end of record r - 1 to the sequence of record r: with a caller's table
+    in another order, or with every record the same one, the "headers" overlap or are empty.  The fields are then
+    nonsense -- coded, refused as headers or refused as a table -- but every access stays inside the block and the
+    handle works afterwards."""
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_1.fastq"))
+    hdrs = headers_of(raw, recs)
+    rng = np.random.default_rng(3)
+    same = recs.copy()
+    same[:] = recs[len(recs) // 2]
+    for table in (recs[::-1].copy(), recs[rng.permutation(len(recs))], same, recs[:1].repeat(3000)):
+        g = code_on_gpu(ctx, raw, hdrs[0], recs=table)
+        assert g["rc"] in (0, -1) and g.get("headers_rc", 0) in (0, -4, -8), (g["rc"], g.get("headers_rc"))
+    assert_fields_equal(code_on_gpu(ctx, raw, hdrs[0], recs=recs), hdrs, hdrs[0])
