@@ -1,5 +1,7 @@
-"""Fills the @@PLACEHOLDERS@@ of DESIGN.md and profiles/README.md from the committed profile files of a round
-(profiles/<tag>_*), so that every number in the two documents is one the profile files hold.
+"""Fills the profile numbers of DESIGN.md and profiles/README.md from the committed profile files of a round
+(profiles/<tag>_*), so that every such number in the two documents is one the profile files hold.  A number sits between
+two HTML comments, <!--@@KEY@@-->value<!--@@--> (invisible when rendered), so that a later profile round refreshes it in
+place; a bare @@KEY@@ in newly written text is turned into that form.
     python3 tools/fill_docs.py [tag, default r04] [range of `value` across boxes, e.g. "99.6-102.9"]"""
 import csv
 import json
@@ -64,9 +66,13 @@ vals = {
 }
 for path in ("DESIGN.md", "profiles/README.md"):
     s = open(R + path).read()
-    left = set(re.findall(r"@@([A-Z0-9]+)@@", s))
-    for k in left:
-        if k in vals:
-            s = s.replace("@@%s@@" % k, vals[k])
+    seen = set()
+
+    def refill(m):
+        seen.add(m.group(1))
+        return "<!--@@%s@@-->%s<!--@@-->" % (m.group(1), vals.get(m.group(1), m.group(2)))
+
+    s = re.sub(r"<!--@@([A-Z0-9]+)@@-->(.*?)<!--@@-->", refill, s, flags=re.S)
+    s = re.sub(r"(?<!<!--)@@([A-Z0-9]+)@@(?!-->)", lambda m: refill(type("M", (), {"group": lambda self, i: (None, m.group(1), m.group(0))[i]})()), s)
     open(R + path, "w").write(s)
-    print(path, "filled:", sorted(left & set(vals)), "left:", sorted(left - set(vals)))
+    print(path, "filled:", sorted(seen & set(vals)), "unknown keys:", sorted(seen - set(vals)))
