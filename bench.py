@@ -299,6 +299,49 @@ def other_data(F, O, device, lanes, steps, kind, mode, total_mib, block_mib, sam
     return out
 
 
+def farm_leg(blocks, workers=16, repeat=4, decompress_workers=4):
+    """End to end through the C++ block farm (tools/fqc_tool.cpp over fqcomp28_amd/csrc/process.hpp: the reference's
+    processReads / processArchiveParts, src/process.cpp:32-105): the job's blocks `repeat` times over as a FASTQ file in
+    /tmp, compressed by `workers` threads (file in, archive out: read, upload, GPU parse, header fields and both streams
+    on the GPU, misc coder, write), then once more with --index and restored from that archive.  The clocks are
+    fqc_tool's (the workers' loops; tables and handles are built before).  Not part of `value`."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "_build", "fqc_tool")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tools", "fqc_tool.cpp"), "-L" + os.path.join(ROOT, "fqcomp28_amd"),
+                    "-lfqgpu", "-Wl,-rpath," + os.path.join(ROOT, "fqcomp28_amd"), "-lpthread"], check=True, capture_output=True, timeout=300)
+    tmp = tempfile.mkdtemp(prefix="fq_farm_", dir="/tmp")
+    try:
+        src, arc, back = (os.path.join(tmp, n) for n in ("in.fastq", "a.fqc", "back.fastq"))
+        with open(src, "wb") as fh:
+            for _ in range(repeat):
+                for raw, _recs in blocks:
+                    raw.tofile(fh)
+        size = os.path.getsize(src)
+
+        def tool(*a):
+            r = subprocess.run([exe] + list(a), capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                raise RuntimeError("fqc_tool %s: %s" % (a[0], (r.stdout + r.stderr)[-300:]))
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        c = tool("c", src, arc, "-t", str(workers))
+        plain_bytes = os.path.getsize(arc)
+        ci = tool("c", src, arc, "-t", str(workers), "--index")
+        d = tool("d", arc, back, "-t", str(decompress_workers))
+        same = subprocess.run(["cmp", "-s", src, back]).returncode == 0
+        return {"file_MiB": size >> 20, "block_MiB": 256, "blocks": c["blocks"], "workers": workers,
+                "compress_MBps": round(size / c["seconds"] / MB, 1), "compress_with_index_MBps": round(size / ci["seconds"] / MB, 1),
+                "archive_bytes": plain_bytes, "archive_unchanged_by_index": os.path.getsize(arc) == plain_bytes,
+                "decode_index_bytes": os.path.getsize(arc + ".fqx"), "decompress_workers": decompress_workers,
+                "decompress_indexed_MBps": round(size / d["seconds"] / MB, 1), "roundtrip_equal": same,
+                "what": "fqc_tool c / d on a file in /tmp: read, H2D, GPU parse, header fields + both streams on the GPU, misc coder, write; "
+                        "the clock covers the worker threads' loops"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(blocks, sft, qft, seconds_budget=24.0):
     """The oracle ("port" of the reference loops) timed on the host cores, like the reference's
     thread pool: one workspace per thread, whole blocks per thread (src/process.cpp:46-68, 93-104).
@@ -361,6 +404,7 @@ def main():
     ap.add_argument("--skip-decode", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-host", action="store_true")
+    ap.add_argument("--skip-farm", action="store_true", help="no end-to-end run of the C++ block farm (4 GiB file in /tmp)")
     ap.add_argument("--skip-other-data", action="store_true", help="no binned / constant / configs[3] runs after the timed region")
     ap.add_argument("--skip-strong", action="store_true", help="no configs[2] run (ONE job in 64 MiB blocks dealt over the ranks) after the timed region")
     args = ap.parse_args()
@@ -726,6 +770,12 @@ def main():
         pb.close()
         extra["parser"] = {"host_parse_MBps": round(raw0.size / t_host / MB, 1),
                            "gpu_create_from_raw_MBps_incl_h2d": round(raw0.size / t_gpu / MB, 1), "tables_equal": ok}
+        if layout == "config1" and not args.skip_farm:
+            try:
+                extra["farm"] = farm_leg(blocks)
+                extra["farm_compress_MBps"] = extra["farm"]["compress_MBps"]
+            except Exception as e:   # (a box without g++ or without room in /tmp: the line says so, the run goes on)
+                extra["farm"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
 
     # ---- data that is not the headline config (rank 0, after the timed region; not part of `value`)
     if rank == 0 and not args.skip_other_data:
