@@ -463,12 +463,31 @@ private:
  *  input (CompressedBuffers::chunk_idx), and is only handed out if its checksum holds: the decoder takes the states
  *  in a snapshot as they are (api.hip: index_accept).
  *    "FQX1" | entries as they were claimed: { u32 chunk_idx, u32 0, u64 seq bytes, u64 qual bytes, u64 fnv1a-64 of the
- *    two indexes } seq index | qual index ... | table: n x { u64 offset of the entry } | u64 n | "FQX1" */
+ *    two indexes } seq index | qual index ... | table: n x { u64 offset of the entry } | u64 n | u64 size of the
+ *    archive | u64 fnv1a-64 of the archive's first 64 KiB (block count, first header, tables) | "FQX1"
+ *  The last two words tie the file to ITS archive: a file left behind by an earlier archive of the same name is
+ *  recognised (belongsTo) and not used. */
 class DecodeIndexFile {
 public:
   static path_t pathFor(const path_t &archive_path) { return path_t(archive_path.string() + ".fqx"); }
   static constexpr uint32_t MAGIC = 0x31585146u;  // "FQX1"
-  static constexpr std::size_t HEAD = 32;
+  static constexpr std::size_t HEAD = 32, TAIL = 28;  // entry head; n, archive size, archive hash, magic
+
+  struct Identity {
+    uint64_t size = 0, hash = 0;
+    friend bool operator==(const Identity &a, const Identity &b) { return a.size == b.size && a.hash == b.hash; }
+  };
+  /** of a finished archive file */
+  static Identity identityOf(const path_t &archive_path) {
+    const PosFile f(archive_path, PosFile::Mode::Read);
+    Identity id;
+    id.size = f.size();
+    std::vector<std::byte> head(static_cast<std::size_t>(std::min<uint64_t>(id.size, 64u << 10)));
+    if (!head.empty()) f.readAt(0, head.data(), head.size());
+    id.hash = checksum(head, {});
+    return id;
+  }
+  [[nodiscard]] bool belongsTo(const Identity &archive) const { return identity_ == archive; }
 
   /** to write (Create) or to read an existing one */
   DecodeIndexFile(const path_t &p, PosFile::Mode m) : file_(p, m) {
@@ -480,14 +499,16 @@ public:
     const uint64_t size = file_.size();
     uint32_t magic = 0;
     uint64_t n = 0;
-    if (size < 16) throw std::runtime_error("decode index file: too short");
+    if (size < 4 + TAIL) throw std::runtime_error("decode index file: too short");
     file_.readAt(0, &magic, 4);
     if (magic != MAGIC) throw std::runtime_error("decode index file: not one");
     file_.readAt(size - 4, &magic, 4);
-    file_.readAt(size - 12, &n, 8);
-    if (magic != MAGIC || n > (size - 16) / 8) throw std::runtime_error("decode index file: damaged trailer (was it closed?)");
+    file_.readAt(size - TAIL, &n, 8);
+    file_.readAt(size - TAIL + 8, &identity_.size, 8);
+    file_.readAt(size - TAIL + 16, &identity_.hash, 8);
+    if (magic != MAGIC || n > (size - 4 - TAIL) / 8) throw std::runtime_error("decode index file: damaged trailer (was it closed?)");
     std::vector<uint64_t> offsets(n);
-    end_of_entries_ = size - 12 - 8 * n;
+    end_of_entries_ = size - TAIL - 8 * n;
     if (n) file_.readAt(end_of_entries_, offsets.data(), 8 * n);
     at_.assign(n, 0);
     for (const uint64_t off : offsets) {
@@ -514,12 +535,14 @@ public:
     const std::lock_guard<std::mutex> guard(m_);
     offsets_.push_back(off);
   }
-  /** after the last put: the table and the trailer */
-  void close() {
+  /** after the last put and when the archive is complete: the table and the trailer */
+  void close(const Identity &archive) {
     const uint64_t n = offsets_.size(), at = claim_.load();
     if (n) file_.writeAt(at, offsets_.data(), 8 * n);
     file_.writeAt(at + 8 * n, &n, 8);
-    file_.writeAt(at + 8 * n + 8, &MAGIC, 4);
+    file_.writeAt(at + 8 * n + 8, &archive.size, 8);
+    file_.writeAt(at + 8 * n + 16, &archive.hash, 8);
+    file_.writeAt(at + 8 * n + 24, &MAGIC, 4);
   }
 
   /** the indexes of chunk cb.chunk_idx into cb.decode_index; false: the file has none for it.  Thread-safe. */
@@ -567,6 +590,7 @@ private:
   std::vector<uint64_t> offsets_;   // writing: entries so far
   std::vector<uint64_t> at_;        // reading: entry of chunk idx (0 = none: offset 0 holds the magic)
   uint64_t end_of_entries_ = 0;
+  Identity identity_;               // reading: the archive the file was written for
 };
 
 /** Dataset analysis (src/prepare.cpp:42-47): the tables of the first sample_size_bytes of the file, on the GPU */

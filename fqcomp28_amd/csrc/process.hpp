@@ -186,7 +186,12 @@ inline FarmReport processReads(const path_t &mates1, const path_t &archive_path,
   Archive archive(archive_path, mates1, set.sample_chunk_size, set.devices.at(0));
   FastqReader reader(mates1, set.reading_chunk_size);
   std::unique_ptr<DecodeIndexFile> sidecar;
-  if (set.decode_index) sidecar = std::make_unique<DecodeIndexFile>(DecodeIndexFile::pathFor(archive_path), PosFile::Mode::Create);
+  if (set.decode_index) {
+    sidecar = std::make_unique<DecodeIndexFile>(DecodeIndexFile::pathFor(archive_path), PosFile::Mode::Create);
+  } else {  // what an earlier archive of this name left behind is not this one's
+    std::error_code ec;
+    std::filesystem::remove(DecodeIndexFile::pathFor(archive_path), ec);
+  }
   FarmReport rep = compressFarm(
       archive.meta(), [&](FastqChunk &c) { return reader.readNextChunk(c); },
       [&](const CompressedBuffersDst &cbs) {
@@ -196,7 +201,7 @@ inline FarmReport processReads(const path_t &mates1, const path_t &archive_path,
       [&] { reader.abort(); }, set);
   archive.writeIndex();
   archive.flush();
-  if (sidecar) sidecar->close();
+  if (sidecar) sidecar->close(DecodeIndexFile::identityOf(archive_path));
   return rep;
 }
 
@@ -244,8 +249,13 @@ inline FarmReport processArchiveParts(const path_t &archive_path, const path_t &
   Archive archive(archive_path);
   FastqWriter writer(mates1_out, archive.chunkOffsets());
   std::unique_ptr<DecodeIndexFile> sidecar;
-  if (std::filesystem::exists(DecodeIndexFile::pathFor(archive_path)))
+  if (std::filesystem::exists(DecodeIndexFile::pathFor(archive_path))) {
     sidecar = std::make_unique<DecodeIndexFile>(DecodeIndexFile::pathFor(archive_path), PosFile::Mode::Read);
+    if (!sidecar->belongsTo(DecodeIndexFile::identityOf(archive_path))) {
+      std::fprintf(stderr, "%s was written for another archive: not used\n", DecodeIndexFile::pathFor(archive_path).string().c_str());
+      sidecar.reset();
+    }
+  }
   FarmReport rep = decompressFarm(
       archive.meta(),
       [&](CompressedBuffersSrc &cbs) {

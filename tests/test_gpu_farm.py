@@ -188,6 +188,20 @@ def test_cpp_farm_with_decode_indexes_beside_the_archive(F, tool, tmp_path):
     os.remove(side)
     run_tool(tool, "d", arc, back, "-t", 3)
     assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+    os.remove(back)
+    # an index file that belongs to ANOTHER archive (left behind under the same name) is recognised and not used ...
+    other = tmp_path / "other.fqc"
+    raw2, _ = F.synth_fastq(20 << 20, 2, seed=18)
+    src2 = tmp_path / "in2.fastq"
+    raw2.tofile(src2)
+    run_tool(tool, "c", src2, other, "-t", 2, "-R", 8, "-S", 4, "--index")
+    os.replace(str(other) + ".fqx", side)
+    r = subprocess.run([tool, "d", str(arc), str(back), "-t", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "written for another archive" in r.stderr, (r.stdout, r.stderr)
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), raw)
+    # ... and a compression without --index to a name that has one removes it
+    run_tool(tool, "c", src2, arc, "-t", 2, "-R", 8, "-S", 4)
+    assert not os.path.exists(side)
 
 
 def test_indexed_decode_through_the_host_pointer_calls(F):
