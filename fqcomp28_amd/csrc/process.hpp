@@ -45,6 +45,7 @@ struct Settings {  // the part of src/settings.h:36-50 this path needs, plus the
   /** Extension: compress also writes `<archive>.fqx`, the decode indexes of every block (archive.hpp: DecodeIndexFile;
    *  about 2 % of the archive's size); decompress uses the file whenever it lies beside the archive. */
   bool decode_index = false;
+  unsigned index_stride = 0;  // symbols between two snapshots of a decode index (multiple of 64 Ki; 0 = 1 Mi)
 };
 
 struct InputStats {  // src/report.h
@@ -131,7 +132,7 @@ FarmReport compressFarm(const DatasetMeta &meta, Source &&next_chunk, Sink &&wri
   detail::runWorkers(T, [&](unsigned t) {
     wksp[t] = std::make_unique<CompressionWorkspace>(&meta, set.devices[t % set.devices.size()]);
     wksp[t]->reserve(set.reading_chunk_size);
-    wksp[t]->setDecodeIndex(set.decode_index);
+    wksp[t]->setDecodeIndex(set.decode_index, set.index_stride);
     chunks[t].raw_data.reserve(set.reading_chunk_size);
     buffers[t].seq.reserve(set.reading_chunk_size / 8 + (1u << 20));
     buffers[t].qual.reserve(set.reading_chunk_size / 3 + (1u << 20));

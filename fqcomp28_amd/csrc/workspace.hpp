@@ -313,7 +313,13 @@ public:
 
   /** encodeChunk also leaves cbs.decode_index (extension: a decoder that has it decodes a stream from every
    *  snapshot at once; seq / qual and everything else in cbs are unchanged) */
-  void setDecodeIndex(bool on) { decode_index_ = on; }
+  void setDecodeIndex(bool on, unsigned stride_symbols = 0) {
+    decode_index_ = on;
+    // symbols between two snapshots (a multiple of 64 Ki; 0 = the library's 1 Mi): a stride is what ONE wave decodes, so
+    // a block alone takes a stride's time -- 105 ms at 1 Mi -- and the index grows as the stride shrinks (2 % of the
+    // archive at 1 Mi, 8 % at 256 Ki)
+    if (on && stride_symbols) fqgpuCheck(fqgpu_ctx_set_index_stride(ctx_, stride_symbols), "setDecodeIndex");
+  }
 
   /** Encodes reads into cbs, allocating memory in cbs as needed; mutates the chunk (N -> A).
    *  The chunk may come UNPARSED (records empty, as FastqReader hands it out): the GPU then finds the

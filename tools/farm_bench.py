@@ -31,6 +31,8 @@ with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             if os.path.exists(old):
                 os.remove(old)
         index = ["--index"] if os.environ.get("FARM_INDEX") else []
+        if os.environ.get("FARM_INDEX_STRIDE"):
+            index += ["--index-stride", os.environ["FARM_INDEX_STRIDE"]]
         run = subprocess.run([exe, "c", src, arc, "-t", str(t)] + index, capture_output=True, text=True, check=True)
         c = json.loads(run.stdout.splitlines()[-1])
         wall_c = time.time() - t0

@@ -1,5 +1,6 @@
 // fqc_tool -- the reference's two commands over the GPU block farm (fqcomp28_amd/csrc/process.hpp):
 //   fqc_tool c <in.fastq> <out.fqc> [-t threads] [-R block MiB] [-S sample MiB] [-d dev,dev,...] [--accumulate-n]
+//              [--index [--index-stride Ki symbols, a multiple of 64]]   (extension: decode indexes in <out.fqc>.fqx)
 //   fqc_tool d <in.fqc> <out.fastq> [-t threads] [-d dev,dev,...]
 // (fqcomp28 c --i1 in.fastq -o out.fqc -t N / fqcomp28 d -i out.fqc --o1 out.fastq, src/app.cpp:29-76.)
 // Prints one JSON line with sizes, seconds and blocks per worker.  Needs a GPU: no CPU fallback.
@@ -13,7 +14,7 @@ using namespace fqcomp28;
 
 int main(int argc, char **argv) {
   if (argc < 4 || (strcmp(argv[1], "c") && strcmp(argv[1], "d"))) {
-    std::fprintf(stderr, "usage: fqc_tool c|d <in> <out> [-t N] [-R MiB] [-S MiB] [-d 0,1,..] [--accumulate-n] [--index]\n");
+    std::fprintf(stderr, "usage: fqc_tool c|d <in> <out> [-t N] [-R MiB] [-S MiB] [-d 0,1,..] [--accumulate-n] [--index] [--index-stride KiSymbols]\n");
     return 2;
   }
   Settings set;
@@ -25,6 +26,7 @@ int main(int argc, char **argv) {
     else if (a == "-S") set.sample_chunk_size = (std::size_t)std::atoll(val()) << 20;
     else if (a == "--accumulate-n") set.accumulate_n_buffers = true;
     else if (a == "--index") set.decode_index = true;
+    else if (a == "--index-stride") { set.decode_index = true; set.index_stride = static_cast<unsigned>(std::atoi(val())) << 10; }  // Ki symbols
     else if (a == "-d") {
       set.devices.clear();
       for (const char *p = val(); *p;) { set.devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
