@@ -5,9 +5,13 @@
 //   archive_tool chunks <in.fastq> <bytes>    FastqReader with that reading size: "chunk <idx> <bytes>" per chunk
 //   archive_tool rejoin <in.fastq> <out.fastq> <bytes>   the same chunks through FastqWriter, LAST chunk first
 //                                             (reference test/fastq_io_test.cpp:15-53: reader -> writer identity)
+//   archive_tool threads <in.fqc> <out.fqc> <T> <rounds>   what the farm's workers share, from T threads at once (for
+//                                             ThreadSanitizer): readBlock of one archive -> through a Gate of two ->
+//                                             writeBlock + DecodeIndexFile::put of another, `rounds` times over; then
+//                                             T threads read it back and check every block's index entry
 // tests/test_archive.py drives it against oracle/fqc_archive.py (an independent Python reading of
 // src/archive.h:10-17, src/archive.cpp:57-106).
-#include "../../fqcomp28_amd/csrc/archive.hpp"
+#include "../../fqcomp28_amd/csrc/process.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +99,64 @@ int main(int argc, char **argv) {
         writer.flush();
       }
       return 0;
+    }
+    if (argc == 6 && std::string(argv[1]) == "threads") {
+      const unsigned T = static_cast<unsigned>(std::atoi(argv[4])), rounds = static_cast<unsigned>(std::atoi(argv[5]));
+      // a made-up decode index of a block: a function of its bytes, so that the readers can check what they get
+      const auto fake_index = [](const CompressedBuffers &cb, int s) {
+        std::vector<std::byte> v(64 + (cb.seq.size() + 7 * static_cast<std::size_t>(s)) % 4000);
+        for (std::size_t i = 0; i < v.size(); ++i) v[i] = static_cast<std::byte>((i * 131 + cb.chunk_idx * 7 + cb.qual.size() + static_cast<std::size_t>(s)) & 0xFF);
+        return v;
+      };
+      std::atomic<std::size_t> written{0}, checked{0};
+      {
+        Archive in(argv[2]);
+        DatasetMeta meta(std::string_view(in.meta().first_header));
+        std::memcpy(meta.ft_seq.get(), in.meta().ft_seq.get(), FQGPU_SEQ_FT_BYTES);
+        std::memcpy(meta.ft_qual.get(), in.meta().ft_qual.get(), FQGPU_QUAL_FT_BYTES);
+        const std::size_t per_round = in.nBlocks();
+        Archive out(argv[3], std::move(meta));
+        DecodeIndexFile side(DecodeIndexFile::pathFor(argv[3]), PosFile::Mode::Create);
+        detail::Gate gate(2);
+        std::atomic<unsigned> ticket{0};
+        detail::runWorkers(T, [&](unsigned) {
+          for (;;) {
+            const unsigned k = ticket.fetch_add(1);
+            if (k >= rounds) break;
+            Archive again(argv[2]);  // (every round reads the input from its start)
+            CompressedBuffersSrc cbs;
+            for (;;) {
+              {
+                const detail::Gate::Pass pass(gate);
+                if (!again.readBlock(cbs)) break;
+              }
+              CompressedBuffersDst d = toDst(std::move(cbs));
+              d.chunk_idx = static_cast<uint32_t>(k * per_round + d.chunk_idx);
+              d.decode_index[0] = fake_index(d, 0);
+              d.decode_index[1] = fake_index(d, 1);
+              out.writeBlock(d);
+              side.put(d);
+              written.fetch_add(1);
+            }
+          }
+        });
+        out.writeIndex();
+        out.flush();
+        side.close(DecodeIndexFile::identityOf(argv[3]));
+      }
+      Archive back(argv[3]);
+      const DecodeIndexFile side(DecodeIndexFile::pathFor(argv[3]), PosFile::Mode::Read);
+      if (!side.belongsTo(DecodeIndexFile::identityOf(argv[3]))) throw std::runtime_error("the index file does not know its archive");
+      detail::runWorkers(T, [&](unsigned) {
+        CompressedBuffersSrc cbs;
+        while (back.readBlock(cbs)) {
+          if (!side.get(cbs)) throw std::runtime_error("a block without its index entry");
+          if (cbs.decode_index[0] != fake_index(cbs, 0) || cbs.decode_index[1] != fake_index(cbs, 1)) throw std::runtime_error("an index entry with another block's bytes");
+          checked.fetch_add(1);
+        }
+      });
+      std::printf("threads %u: %zu blocks written, %zu read back with their index entries\n", T, written.load(), checked.load());
+      return written.load() == checked.load() && written.load() > 0 ? 0 : 1;
     }
   } catch (const std::exception &e) {
     std::printf("exception: %s\n", e.what());

@@ -309,6 +309,25 @@ def test_container_reader_and_writer_are_clean_under_asan_and_ubsan(F, tool, too
         assert run(tool_sanitized, "dump", cut).returncode == 1
 
 
+def test_what_the_farms_workers_share_is_clean_under_thread_sanitizer(F, tmp_path, golden_dir):
+    """Archive::readBlock / writeBlock, DecodeIndexFile::put / get and the read Gate from six threads at once under
+    ThreadSanitizer (the farm itself needs a GPU; these are the objects its workers share): every block comes back
+    with its own index entry, no data race reported."""
+    exe = str(tmp_path / "archive_tool_tsan")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "archive_tool.cpp"),
+                        "-L" + os.path.join(ROOT, "fqcomp28_amd"), "-lfqgpu", "-Wl,-rpath," + os.path.join(ROOT, "fqcomp28_amd"), "-lpthread"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for g++ here: " + r.stderr[-200:])
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_1.fastq"))
+    src = str(tmp_path / "in.fqc")
+    oracle_archive(F, src, raw, recs, 6, order=[3, 0, 5, 1, 4, 2])
+    r = subprocess.run([exe, "threads", src, str(tmp_path / "out.fqc"), "6", "12"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0"))
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr[-3000:]
+    assert "72 blocks written, 72 read back" in r.stdout
+
+
 def test_misc_coder_decodes_or_refuses_damaged_streams_under_asan_and_ubsan(tmp_path):
     """tests/cpp/misc_fuzz.cpp: fq_misc.cpp compiled with the sanitizers; round trips of the container's stream
     shapes, then thousands of truncated / bit-flipped / random streams into exact-size buffers."""
