@@ -1032,11 +1032,18 @@ def test_handles_created_and_destroyed_in_a_loop_give_all_device_memory_back(F):
         return f.value
     raw, recs = _synth(F, 2, 24 << 20)
     _, _, sft, qft = O.freq_tables(raw, recs)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import headers_oracle as HO
+    first = raw.tobytes()[: int(recs[0]["seq_off"]) - 1]
+    types, seps = HO.format_from_header(first)
+    fmt = ([0 if t == HO.NUMERIC else 1 for t in types], bytes(seps), first)
     def cycle():
         ctx = F.Context(sft, qft)
         ctx.set_lanes(1)
-        g = ctx.encode_raw(raw)   # fqgpu_encode_begin(recs = NULL): table built on the device
-        assert g["rc"] == 0 and len(g["recs"]) == len(recs)
+        # fqgpu_encode_begin(recs = NULL): table built on the device; the header fields coded there too; a decode index
+        g = ctx.encode_raw(raw, flags=F.F_DECODE_INDEX, header_format=fmt)
+        assert g["rc"] == 0 and g["headers_rc"] == 0 and len(g["recs"]) == len(recs) and g["index"][1].size > 32
         ctx.close()
     cycle()   # first use: the runtime's own pools, code objects, the pinned cache
     F.lib().fqgpu_host_trim()
