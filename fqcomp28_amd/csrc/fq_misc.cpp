@@ -177,10 +177,29 @@ extern "C" size_t fqgpu_memcompress(uint8_t *dst, size_t dst_cap, const uint8_t 
     memcpy(dst + 1, src, src_size);
     return src_size + 1;
   }
-  // plane histograms for stride 4; strides 2 and 1 are sums of them
+  // plane histograms for stride 4; strides 2 and 1 are sums of them.  Eight bytes at a time, and a run of equal
+  // 8-byte words is counted in one go: most of a block's side streams are (nearly) constant -- read lengths, N counts,
+  // "+1" read numbers, "same as before" flags -- and a counter that is incremented again before its last store has
+  // retired costs a store-forwarding round trip per byte (10 ms per 256 MiB block of the farm went into this loop)
   Plane p4[4], p2[2], p1;
   memset(p4, 0, sizeof(p4));
-  for (size_t i = 0; i < src_size; i++) p4[i & 3].count[src[i]]++;
+  {
+    size_t i = 0;
+    while (i + 8 <= src_size) {
+      uint64_t w;
+      memcpy(&w, src + i, 8);
+      size_t run = 1;
+      while (i + 8 * (run + 1) <= src_size) {
+        uint64_t v;
+        memcpy(&v, src + i + 8 * run, 8);
+        if (v != w) break;
+        run++;
+      }
+      for (int k = 0; k < 8; k++) p4[k & 3].count[src[i + k]] += (uint32_t)run;  // (i is a multiple of 8: byte k lies in plane k & 3)
+      i += 8 * run;
+    }
+    for (; i < src_size; i++) p4[i & 3].count[src[i]]++;
+  }
   for (int k = 0; k < 4; k++) p4[k].n = (src_size + 3 - (size_t)k) / 4;
   memset(p2, 0, sizeof(p2));
   memset(&p1, 0, sizeof(p1));
