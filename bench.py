@@ -405,6 +405,8 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-host", action="store_true")
     ap.add_argument("--skip-farm", action="store_true", help="no end-to-end run of the C++ block farm (4 GiB file in /tmp)")
+    ap.add_argument("--all-legs", action="store_true", help="N > 1: also the rank-0 legs that describe ONE GPU and its host (CPU baseline and oracle check, "
+                    "host-pointer path, other data); by default they run at N = 1 only")
     ap.add_argument("--skip-other-data", action="store_true", help="no binned / constant / configs[3] runs after the timed region")
     ap.add_argument("--skip-strong", action="store_true", help="no configs[2] run (ONE job in 64 MiB blocks dealt over the ranks) after the timed region")
     args = ap.parse_args()
@@ -430,6 +432,10 @@ def main():
     device = local
     layout = args.layout if args.layout != "auto" else ("config1" if world == 1 else "weak")
     block_mib = args.block_mib or (64 if layout == "strong" else 256)
+    if world > 1 and not args.all_legs:
+        # what describes one GPU and the box's host cores is measured at N = 1 (the CPU baseline is "rank 0 at N = 1 only"):
+        # the N > 1 runs keep to the timed region, the configs[2] job and the decode of the archive dealt over the ranks
+        args.skip_cpu = args.skip_host = args.skip_other_data = True
 
     def barrier():
         farm.barrier(dist)
