@@ -9,6 +9,8 @@
 //                                             ThreadSanitizer): readBlock of one archive -> through a Gate of two ->
 //                                             writeBlock + DecodeIndexFile::put of another, `rounds` times over; then
 //                                             T threads read it back and check every block's index entry
+//   archive_tool sidecheck <in.fqc>           the decode index file beside an archive: "foreign" if it was written for
+//                                             another archive, else every block's entry read (checksums) and counted
 // tests/test_archive.py drives it against oracle/fqc_archive.py (an independent Python reading of
 // src/archive.h:10-17, src/archive.cpp:57-106).
 #include "../../fqcomp28_amd/csrc/process.hpp"
@@ -98,6 +100,18 @@ int main(int argc, char **argv) {
         if (argc > 5 && argv[5][0] == 'a') return 3;  // "abandon": leave without flush() -- no output file may remain
         writer.flush();
       }
+      return 0;
+    }
+    if (argc == 3 && std::string(argv[1]) == "sidecheck") {
+      Archive in(argv[2]);
+      const DecodeIndexFile side(DecodeIndexFile::pathFor(argv[2]), PosFile::Mode::Read);
+      if (!side.belongsTo(DecodeIndexFile::identityOf(argv[2]))) { std::printf("foreign\n"); return 0; }
+      CompressedBuffersSrc cbs;
+      std::size_t with = 0, without = 0, bytes = 0;
+      while (in.readBlock(cbs)) {
+        if (side.get(cbs)) { ++with; bytes += cbs.decode_index[0].size() + cbs.decode_index[1].size(); } else ++without;
+      }
+      std::printf("entries %zu missing %zu bytes %zu\n", with, without, bytes);
       return 0;
     }
     if (argc == 6 && std::string(argv[1]) == "threads") {

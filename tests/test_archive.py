@@ -328,6 +328,54 @@ def test_what_the_farms_workers_share_is_clean_under_thread_sanitizer(F, tmp_pat
     assert "72 blocks written, 72 read back" in r.stdout
 
 
+def test_decode_index_file_damaged_truncated_foreign_under_asan_and_ubsan(F, tool_sanitized, tmp_path, golden_dir):
+    """archive.hpp's DecodeIndexFile (the farm's `<archive>.fqx`) with the sanitizers on: written by six threads, read back
+    whole; then every kind of damage -- a bit in an entry's bytes, in an entry's head, in the table, in the trailer, the file
+    cut at many lengths, random bytes -- is refused with an exception (exit 1), never a sanitizer report; a file that belongs
+    to another archive says so."""
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    raw, recs = O.load_fastq(os.path.join(golden_dir, "SRR065390_sub_1.fastq"))
+    src, arc = str(tmp_path / "in.fqc"), str(tmp_path / "out.fqc")
+    oracle_archive(F, src, raw, recs, 5, order=[2, 0, 4, 1, 3])
+
+    def run(*args):
+        r = subprocess.run([tool_sanitized, *args], capture_output=True, text=True, env=env, timeout=120)
+        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+        return r
+    assert run("threads", src, arc, "6", "3").returncode == 0
+    r = run("sidecheck", arc)
+    assert r.returncode == 0 and r.stdout.startswith("entries 15 missing 0"), r.stdout
+    side = arc + ".fqx"
+    good = open(side, "rb").read()
+    rng = np.random.default_rng(5)
+    places = [10, 40, 100, len(good) // 2, len(good) - 150, len(good) - 30, len(good) - 20, len(good) - 10, len(good) - 2]
+    refused = 0
+    for at in places + [int(x) for x in rng.integers(4, len(good), 40)]:
+        bad = bytearray(good)
+        bad[at] ^= 1 << int(rng.integers(8))
+        open(side, "wb").write(bad)
+        r = run("sidecheck", arc)
+        assert r.returncode in (0, 1), (at, r.stdout, r.stderr[-500:])
+        if r.returncode == 1:
+            assert "decode index file" in r.stdout, (at, r.stdout)
+            refused += 1
+        else:  # (a bit of the identity words: the file then looks like another archive's; padding bytes of an entry head)
+            assert r.stdout.startswith("foreign") or r.stdout.startswith("entries 15 missing 0"), (at, r.stdout)
+    assert refused >= 40
+    for cut in [0, 3, 4, 20, 31, 32, len(good) // 3, len(good) - 29, len(good) - 28, len(good) - 1]:
+        open(side, "wb").write(good[:cut])
+        r = run("sidecheck", arc)
+        assert r.returncode == 1 and "decode index file" in r.stdout, (cut, r.stdout, r.stderr[-300:])
+    for _ in range(10):
+        open(side, "wb").write(good[:4] + bytes(rng.integers(0, 256, len(good) - 8, dtype=np.uint8)) + good[-4:])
+        assert run("sidecheck", arc).returncode in (0, 1)
+    # the index file of ANOTHER archive under this one's name
+    other = str(tmp_path / "other.fqc")
+    assert run("threads", src, other, "2", "1").returncode == 0
+    os.replace(other + ".fqx", side)
+    assert run("sidecheck", arc).stdout.startswith("foreign")
+
+
 def test_misc_coder_decodes_or_refuses_damaged_streams_under_asan_and_ubsan(tmp_path):
     """tests/cpp/misc_fuzz.cpp: fq_misc.cpp compiled with the sanitizers; round trips of the container's stream
     shapes, then thousands of truncated / bit-flipped / random streams into exact-size buffers."""
