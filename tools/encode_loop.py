@@ -1,5 +1,6 @@
 """The timed encode loop alone on one kind of data, for profilers:
-    rocprofv3 --kernel-trace --stats -- python3 tools/encode_loop.py [synth|real|binned|constant|config3|config4] [steps] [lanes]"""
+    rocprofv3 --kernel-trace --stats -- python3 tools/encode_loop.py [synth|real|binned|constant|config3|config4] [steps] [lanes] [quality segment] [sequence segment]
+(lanes 0 = the library's default; segments 0 = the library's defaults)"""
 import os
 import sys
 import time
@@ -24,6 +25,10 @@ else:
 sft, qft = bench.sample_tables(F, blocks, 128 << 20, 0)
 ctx = F.Context(sft, qft)
 ctx.set_lanes(lanes)
+qseg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+sseg = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+if qseg or sseg:
+    ctx.set_chain_params(segment=qseg, seq_segment=sseg or None)
 db = [ctx.dblock(raw, recs) for raw, recs in blocks]
 for b in db:
     b.encode()
