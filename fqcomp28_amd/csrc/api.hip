@@ -276,9 +276,36 @@ extern "C" int fqgpu_ctx_last_timing(fqgpu_ctx *ctx, fqgpu_timing *out) {
 }
 
 // ------------------------------------------------------------------ encode lanes
-EncLane *fq_next_lane(fqgpu_ctx *ctx, size_t n_bases) {
-  EncLane &l = ctx->lanes[ctx->next_lane % fq_lanes_for(ctx, n_bases)];
-  ctx->next_lane++;
+// Blocks take the lanes in turn -- unless the handle keeps coding the SAME few blocks (no more of them than lanes): then
+// a block goes back to the lane of its last encode.  Its encodes are ordered anyway (same streams, same result words: ev_encoded),
+// and on its own lane that order costs nothing, where the rotation sends the next encode to another lane that must also finish
+// ANOTHER block's encode first: the chains of unrelated blocks get coupled and every step ends in a partial barrier -- four blocks
+// coded over and over on six lanes ran at 56-58 GB/s against 69 on their own four.  With more blocks than lanes the rotation
+// stays: a fixed assignment (sixteen blocks: 3 3 3 3 2 2) leaves two lanes idle at the end of a batch.
+// `b` is only compared with the blocks coded last, never followed (it may be gone); nullptr: reserving, lanes in turn.
+EncLane *fq_next_lane(fqgpu_ctx *ctx, size_t n_bases, fqgpu_dblock *b) {
+  const unsigned n = fq_lanes_for(ctx, n_bases);
+  unsigned pick = n;
+  if (b) {
+    unsigned distinct = 0;
+    bool seen = false;
+    for (unsigned i = 0; i < FQ_RECENT_BLOCKS; i++) {
+      const void *p = ctx->recent[i];
+      if (!p) continue;
+      bool first = true;
+      for (unsigned j = 0; j < i; j++) first = first && ctx->recent[j] != p;
+      distinct += first;
+      seen = seen || p == b;
+    }
+    ctx->recent[ctx->recent_at++ % FQ_RECENT_BLOCKS] = b;
+    if (seen && distinct <= n && b->home_lane >= 0 && (unsigned)b->home_lane < n) pick = (unsigned)b->home_lane;
+  }
+  if (pick == n) {
+    pick = ctx->next_lane % n;
+    ctx->next_lane++;
+  }
+  if (b) b->home_lane = (int)pick;
+  EncLane &l = ctx->lanes[pick];
   if (!l.st_seq) {
     // Both pipelines at the same priority: while the sequence chains were serial their stream
     // ran at high priority; with every kernel a throughput kernel that costs 2 % (measured).
@@ -641,6 +668,7 @@ extern "C" void fqgpu_dblock_destroy(fqgpu_dblock *b) {
   (void)hipSetDevice(b->device);
   void *ps[] = {b->raw, b->recs, b->seq, b->qual, b->readlens, b->n_count, b->n_pos, b->result, b->index[0], b->index[1]};
   for (void *p : ps) if (p) (void)hipFree(p);
+  if (b->ev_encoded) (void)hipEventDestroy(b->ev_encoded);
   delete b;
 }
 

@@ -622,13 +622,14 @@ int fq_qual_counts_sorted(hipStream_t st, const uint8_t *raw_dev, const fqgpu_re
 int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t wait, hipStream_t *done, bool reserve_only) {
   const unsigned R = (unsigned)b->n_recs;
   if (R == 0 || b->n_bases == 0) return FQGPU_E_ARG;
-  EncLane *lp = fq_next_lane(ctx, b->n_bases);
+  EncLane *lp = fq_next_lane(ctx, b->n_bases, reserve_only ? nullptr : b);  // (reserving walks the lanes in turn)
   if (!lp) return FQGPU_E_NOMEM;
   EncLane &lane = *lp;
   hipStream_t st = lane.st_seq;
   if (done) *done = st;
   int rc;
   if (wait) FQ_HIP(hipStreamWaitEvent(st, wait, 0));
+  if (!reserve_only && b->ev_encoded) FQ_HIP(hipStreamWaitEvent(st, b->ev_encoded, 0));  // the block's previous encode (fqgpu_internal.h)
   if ((rc = lane.rec_start.reserve((size_t)(R + 1) * 4))) return rc;
   if ((rc = lane.n_cnt32.reserve((size_t)R * 4 * 2))) return rc;  // n_cnt32 | lens32
   if ((rc = lane.n_off.reserve((size_t)(R + 1) * 4))) return rc;
@@ -713,5 +714,7 @@ int fq_encode_launch(fqgpu_ctx *ctx, fqgpu_dblock *b, unsigned flags, hipEvent_t
                      lane.n_off.as<uint32_t>(), b->n_pos, (flags & FQGPU_F_WRITE_BACK_N) ? 1 : 0);
   FQ_SPAN_END();
   FQ_HIP(hipGetLastError());
+  if (!b->ev_encoded) FQ_HIP(hipEventCreateWithFlags(&b->ev_encoded, hipEventDisableTiming));
+  FQ_HIP(hipEventRecord(b->ev_encoded, st));
   return FQGPU_OK;
 }

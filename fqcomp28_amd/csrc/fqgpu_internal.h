@@ -174,6 +174,7 @@ struct EncLane {
 };
 
 #define FQ_MAX_LANES 8
+#define FQ_RECENT_BLOCKS 8
 
 struct fqgpu_ctx {
   int device = 0;
@@ -192,6 +193,8 @@ struct fqgpu_ctx {
   unsigned n_cus = 256;          // compute units of the device
   unsigned setfunc_wgs = 0;      // persistent workgroups of k_seq_setfunc (0 = default, see fqgpu_ctx_create)
   unsigned n_lanes = 0, next_lane = 0;  // n_lanes 0 = by block size: fq_lanes_for()
+  const void *recent[FQ_RECENT_BLOCKS] = {};  // the blocks coded last (compared, never followed: api.hip fq_next_lane)
+  unsigned recent_at = 0;
   EncLane lanes[FQ_MAX_LANES];
   // decode scratch
   DevBuf n_cnt32, n_off, scan_tmp;
@@ -211,7 +214,7 @@ struct fqgpu_ctx {
   HdrScratch hp_hdr;                  // fqgpu_encode_headers_*: the header fields of the block in flight
 };
 
-EncLane *fq_next_lane(fqgpu_ctx *ctx, size_t n_bases);  // api.hip: round-robin, creates streams on first use
+EncLane *fq_next_lane(fqgpu_ctx *ctx, size_t n_bases, fqgpu_dblock *b = nullptr);  // api.hip: the next lane in turn or the block's own; creates streams on first use
 // Blocks a handle keeps in flight when the caller has not said (fqgpu_ctx_set_lanes(ctx, 0), the default): four -- two
 // already fill the chip with 256 MiB blocks --, six for blocks of less than 48 M symbols (about 100 MiB), whose chains of
 // short kernels leave more gaps to fill: 16 x 64 MiB blocks 70.6 -> 75.6 GB/s (eight: 71.2).
@@ -235,6 +238,12 @@ struct fqgpu_dblock {
   BlockResult *result = nullptr;  // device
   BlockResult host_result;        // filled by fqgpu_sync-ing calls
   size_t seq_len = 0, qual_len = 0, n_pos_len = 0;  // stream sizes used by decode
+  // "the block's last encode is through", recorded behind its last kernel: the next encode of the SAME block -- on whichever lane it
+  // lands -- waits for it, so that two encodes of one block never write its streams and result words at the same time (a caller
+  // that queues a block again without a sync in between, with more lanes than blocks; recorded on and waited for by streams of
+  // one lane it is free)
+  hipEvent_t ev_encoded = nullptr;
+  int home_lane = -1;  // the lane of the block's last encode (api.hip: fq_next_lane)
   int last_op = 0;  // 1 = encode, 2 = decode: which fields of the result block are meaningful
   bool result_pulled = true;  // host_result / stream sizes reflect the last launched operation
   // decode index (extension): device copy per stream, valid bytes, allocated bytes
