@@ -33,7 +33,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")  # up to 8 blocks in flight x (seq, qual) streams, one hardware queue each
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 8 blocks in flight x (seq, qual) streams, one hardware queue each
 
 import numpy as np  # noqa: E402
 

@@ -11,19 +11,17 @@
 #include <mutex>
 #include <vector>
 
-// The encode lanes of ONE handle use up to 16 streams (two per block in flight: sequence and quality pipelines).  ROCm maps
-// streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue run back to back; ask
-// for 32 before the runtime initialises.  Sixteen were enough for one handle -- and made every handle created behind it 9 %
-// slower (its streams shared the first one's queues: 70.9 against 77.6 GB/s on sixteen 64 MiB blocks; 78.6 once the first
-// handle was destroyed; 77.8 with 32 queues: tools/second_handle_probe.py), which is what a process with several workers
-// looks like.  One handle alone: 10.66 against 10.63 ms per step of BASELINE's 1 GiB (six interleaved runs each).  This touches the
+// The encode lanes use up to 16 streams (two per block in flight: sequence and quality pipelines).  ROCm maps streams onto
+// GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
+// run back to back; ask for 16 before the runtime initialises (one per stream of 8 lanes;
+// 24 helps blocks of 16 MiB and less by a fifth and costs 256 MiB blocks 2 %).  This touches the
 // host process's environment, so it is narrow and can be switched off: it never overrides a value
 // the application (or the user) set, it has no effect once HIP is initialised, and
 // FQGPU_KEEP_HW_QUEUES=1 in the environment makes the library leave the variable alone
 // ("Environment").
 __attribute__((constructor)) static void fq_ask_for_hw_queues() {
   if (getenv("FQGPU_KEEP_HW_QUEUES")) return;
-  setenv("GPU_MAX_HW_QUEUES", "32", 0);
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
 // ------------------------------------------------------------------ errors

@@ -18,7 +18,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np  # noqa: E402
 
 

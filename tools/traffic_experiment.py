@@ -11,7 +11,7 @@ sys.path.insert(0, ".")
 # the switches exist only in the experiments build of the library (make experiments)
 subprocess.run(["make", "-C", "fqcomp28_amd/csrc", "-j", "6", "experiments"], check=True, stdout=subprocess.DEVNULL)
 os.environ["FQGPU_LIB"] = os.path.abspath("tools/_build/libfqgpu_experiments.so")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ.setdefault("FQGPU_DEBUG_NO_ALIAS", "1")
 import fqcomp28_amd as F
 import bench
