@@ -597,15 +597,6 @@ def main():
                 "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
 
     extra = {}
-    # ---- BASELINE configs[2] at every N (after the timed region; all ranks): the reference's own scaling config
-    if not args.skip_strong and layout != "strong":
-        sc2 = strong_config2(F, farm, dist, rank, world, device, max(0, min(args.lanes, 8)), max(3, args.steps), 1024, 64, args.sample_mib,
-                             None if args.skip_cpu else _oracle())
-        extra["strong_config2_MBps"] = sc2["MBps"]
-        extra["strong_config2"] = sc2
-        if world == 1:
-            extra["encode_config3_MBps"] = sc2["MBps"]   # 16 x 64 MiB on one GPU: the same run under the name the blocks' size gives it
-
     # ---- decode (after the timed region): the same archive, blocks dealt over the ranks exactly as
     # they were coded (configs[4]); then extensions: decode index, many small blocks
     if not args.skip_decode:
@@ -697,6 +688,21 @@ def main():
     for b in dblocks:
         b.close()
     dblocks = []
+    # The timed handle goes before the next one comes: a handle created behind another shares the first one's hardware
+    # queues (GPU_MAX_HW_QUEUES = 16: streams on one queue run back to back) and runs 5-9 % slower for it -- until round 4's
+    # last day every later leg of this process paid that (tools/second_handle_probe.py).
+    ctx.close()
+    ctx = None
+
+    # ---- BASELINE configs[2] at every N (after the timed region; all ranks): the reference's own scaling config
+    if not args.skip_strong and layout != "strong":
+        sc2 = strong_config2(F, farm, dist, rank, world, device, max(0, min(args.lanes, 8)), max(3, args.steps), 1024, 64, args.sample_mib,
+                             None if args.skip_cpu else _oracle())
+        extra["strong_config2_MBps"] = sc2["MBps"]
+        extra["strong_config2"] = sc2
+        if world == 1:
+            extra["encode_config3_MBps"] = sc2["MBps"]   # 16 x 64 MiB on one GPU: the same run under the name the blocks' size gives it
+
 
     # ---- the callers either side of the path (not part of `value`): the host-pointer call incl.
     # PCIe -- what CompressionWorkspace::encodeChunk gets through the shim -- from T worker threads with
@@ -705,7 +711,8 @@ def main():
     if rank == 0 and not args.skip_host:
         T = max(1, args.host_threads)
         per_thread = max(1, (len(blocks) * 4 + T - 1) // T)   # the job's blocks four times over in total
-        ctxs = [ctx] + [F.Context(sft, qft, device=device) for _ in range(T - 1)]
+        ctxs = [F.Context(sft, qft, device=device) for _ in range(T)]
+        hctx = ctxs[0]
         for c in ctxs:
             c.set_lanes(1)
         pins = []
@@ -743,18 +750,18 @@ def main():
         # one thread, pageable buffers: what a caller that changes nothing gets
         raw0 = np.array(blocks[0][0], dtype=np.uint8, copy=True)
         recs0 = blocks[0][1]
-        bufs0 = ctx.host_buffers(len(recs0), int(recs0["len"].sum()))
+        bufs0 = hctx.host_buffers(len(recs0), int(recs0["len"].sum()))
         best = None
         for _ in range(3):
             t0 = time.perf_counter()
-            got = ctx.encode_block_into(raw0, recs0, bufs0)
+            got = hctx.encode_block_into(raw0, recs0, bufs0)
             d1 = time.perf_counter() - t0
             assert got[0] == 0
             best = d1 if best is None else min(best, d1)
         # a host-pointer result of the T-thread run against the resident path's streams of the same block, byte for byte
         t_chk = 0
         hp_bufs = pins[t_chk][2]
-        ref_b = ctx.dblock(*blocks[t_chk % len(blocks)])
+        ref_b = hctx.dblock(*blocks[t_chk % len(blocks)])
         ref_b.encode()
         ref = ref_b.fetch()
         ref_b.close()
@@ -763,19 +770,20 @@ def main():
                                  "includes": "H2D of the block + record table, encode, D2H of both streams and the side streams",
                                  "one_thread_pageable_MBps": round(raw0.size / best / MB, 1),
                                  "streams_equal_resident_path": same_hp}
-        for c in ctxs[1:]:
-            c.close()
+
         t0 = time.perf_counter()
         hr = F.parse_fastq(raw0)
         t_host = time.perf_counter() - t0
         t0 = time.perf_counter()
-        pb = ctx.dblock(raw0)  # H2D + newline scan + record table on the GPU
-        ctx.sync()
+        pb = hctx.dblock(raw0)  # H2D + newline scan + record table on the GPU
+        hctx.sync()
         t_gpu = time.perf_counter() - t0
         ok = bool(np.array_equal(pb.records(), hr))
         pb.close()
         extra["parser"] = {"host_parse_MBps": round(raw0.size / t_host / MB, 1),
                            "gpu_create_from_raw_MBps_incl_h2d": round(raw0.size / t_gpu / MB, 1), "tables_equal": ok}
+        for c in ctxs:
+            c.close()
         if layout == "config1" and not args.skip_farm:
             try:
                 extra["farm"] = farm_leg(blocks)
@@ -838,7 +846,6 @@ def main():
             line["gpu_over_cpu_all_cores"] = round(enc_MBps / cpu["value"], 1)
             line["gpu_over_cpu_1_thread"] = round(enc_MBps / cpu["single_thread_MBps"], 1)
         print(json.dumps(line))
-    ctx.close()
     if dist is not None:
         farm.barrier(dist)  # rank 0 runs the checks and baselines alone: the others wait for it here
         dist.destroy_process_group()
